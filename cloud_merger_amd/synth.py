@@ -1,0 +1,132 @@
+"""Seeded synthetic frames for the BASELINE.json configurations.
+
+The reference ships no point data (my_cloud_fusion/data holds only an RViz layout), so every
+input is generated here from numpy.random.Generator(PCG64(seed)).
+"""
+from typing import List, Tuple
+
+import numpy as np
+
+from .types import MergeParams, SensorCloud, XYZI_DTYPE, REF_ROI_MIN, REF_ROI_MAX
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def random_quaternion(rng) -> np.ndarray:
+    q = rng.standard_normal(4)
+    return q / np.linalg.norm(q)
+
+
+def yaw_quaternion(yaw) -> np.ndarray:
+    return np.array([0.0, 0.0, np.sin(yaw / 2), np.cos(yaw / 2)])
+
+
+def ground_scene(rng, n, half_xy, z_lo, z_hi, ground_z=-1.5, ground_sigma=0.03, ground_frac=0.7):
+    """70 % noisy ground plane, 30 % uniform clutter, in the sensor frame; intensity U[0,255]."""
+    ng = int(round(n * ground_frac))
+    xyz = np.empty((n, 3), dtype=np.float64)
+    xyz[:, :2] = rng.uniform(-half_xy, half_xy, size=(n, 2))
+    xyz[:ng, 2] = rng.normal(ground_z, ground_sigma, size=ng)
+    xyz[ng:, 2] = rng.uniform(z_lo, z_hi, size=n - ng)
+    inten = rng.uniform(0.0, 255.0, size=n)
+    perm = rng.permutation(n)
+    return xyz[perm].astype(np.float32), inten[perm].astype(np.float32)
+
+
+def pack(xyz, inten, layout="xyzi16") -> Tuple[np.ndarray, dict]:
+    """Wire layouts: 'xyzi16' (x,y,z,i @0,4,8,12), 'xyz12' (no intensity), 'pcl32' (PCL PointXYZI
+    image, i @16), 'velo22' (x,y,z,i @0,4,8,12 + ring u16 @16 + time f32 @18: unaligned step)."""
+    n = len(xyz)
+    if layout == "xyzi16":
+        a = np.zeros(n, dtype=XYZI_DTYPE)
+        a["x"], a["y"], a["z"], a["intensity"] = xyz[:, 0], xyz[:, 1], xyz[:, 2], inten
+        return a, dict(point_step=16, off_x=0, off_y=4, off_z=8, off_i=12)
+    if layout == "xyz12":
+        return np.ascontiguousarray(xyz, dtype="<f4"), dict(point_step=12, off_x=0, off_y=4, off_z=8, off_i=None)
+    if layout == "pcl32":
+        a = np.zeros((n, 8), dtype="<f4")
+        a[:, :3], a[:, 3], a[:, 4] = xyz, 1.0, inten
+        return a, dict(point_step=32, off_x=0, off_y=4, off_z=8, off_i=16)
+    if layout == "velo22":
+        raw = np.zeros((n, 22), dtype=np.uint8)
+        raw[:, 0:12] = np.ascontiguousarray(xyz, dtype="<f4").view(np.uint8).reshape(n, 12)
+        raw[:, 12:16] = np.ascontiguousarray(inten, dtype="<f4").view(np.uint8).reshape(n, 4)
+        raw[:, 16:18] = (np.arange(n) % 32).astype("<u2").view(np.uint8).reshape(n, 2)
+        raw[:, 18:22] = np.linspace(0, 0.1, n).astype("<f4").view(np.uint8).reshape(n, 4)
+        return raw, dict(point_step=22, off_x=0, off_y=4, off_z=8, off_i=12)
+    raise ValueError(layout)
+
+
+def config1(n_per_sensor=100_000, min_pts=0) -> Tuple[List[SensorCloud], MergeParams]:
+    """2 x 100 k XYZ (no intensity), identity tf, 10 cm voxel — the reference's CPU-runnable case."""
+    sensors = []
+    for s in range(2):
+        rng = _rng(1001 + s)
+        xyz = np.stack([rng.uniform(-10, 10, n_per_sensor), rng.uniform(-10, 10, n_per_sensor),
+                        rng.uniform(-1, 3, n_per_sensor)], axis=1).astype(np.float32)
+        data, lay = pack(xyz, None, "xyz12")
+        sensors.append(SensorCloud(data=data, n=n_per_sensor, **lay))
+    return sensors, MergeParams(leaf=(0.1,) * 3, min_points_per_voxel=min_pts)
+
+
+def config2(n_per_sensor=1_000_000, n_sensors=4, min_pts=0, layout="xyzi16"):
+    """4 x 1 M XYZI, random SE(3) per sensor, 5 cm voxel — the headline configuration."""
+    sensors = []
+    for s in range(n_sensors):
+        rng = _rng(2001 + s)
+        q = random_quaternion(rng)
+        t = rng.uniform(-2, 2, 3)
+        xyz, inten = ground_scene(rng, n_per_sensor, 14.0, -2.0, 4.0)
+        data, lay = pack(xyz, inten, layout)
+        sensors.append(SensorCloud(data=data, n=n_per_sensor, q_xyzw=q, t_xyz=t, **lay))
+    return sensors, MergeParams(leaf=(0.05,) * 3, min_points_per_voxel=min_pts)
+
+
+def config3(n_per_sensor=2_000_000, n_sensors=8, min_pts=0, leaf=0.02):
+    """8 x 2 M, yaw-only rotations, reference ROI crop, 2 cm voxel."""
+    sensors = []
+    for s in range(n_sensors):
+        rng = _rng(3001 + s)
+        q = yaw_quaternion(rng.uniform(-np.pi, np.pi))
+        t = rng.uniform(-2, 2, 3)
+        xyz, inten = ground_scene(rng, n_per_sensor, 40.0, -2.0, 6.0)
+        data, lay = pack(xyz, inten, "xyzi16")
+        sensors.append(SensorCloud(data=data, n=n_per_sensor, q_xyzw=q, t_xyz=t, **lay))
+    return sensors, MergeParams(leaf=(leaf,) * 3, min_points_per_voxel=min_pts,
+                                crop_min=REF_ROI_MIN, crop_max=REF_ROI_MAX)
+
+
+def config5_shard(rank, world, n_per_sensor=4_000_000, n_sensors=16, min_pts=0, leaf=0.01):
+    """16 x 4 M, 1 cm voxel, crop x[-15,45] y[-5,5] z[-0.5,3] (keeps PCL's int32 index valid);
+    this rank's share of the sensors."""
+    mine = [s for s in range(n_sensors) if s % world == rank]
+    sensors = []
+    for s in mine:
+        rng = _rng(5001 + s)
+        q = yaw_quaternion(rng.uniform(-np.pi, np.pi))
+        t = rng.uniform(-2, 2, 3)
+        xyz, inten = ground_scene(rng, n_per_sensor, 40.0, -2.0, 6.0)
+        data, lay = pack(xyz, inten, "xyzi16")
+        sensors.append(SensorCloud(data=data, n=n_per_sensor, q_xyzw=q, t_xyz=t, **lay))
+    return sensors, MergeParams(leaf=(leaf,) * 3, min_points_per_voxel=min_pts,
+                                crop_min=(-15.0, -5.0, -0.5), crop_max=(45.0, 5.0, 3.0))
+
+
+def velodyne_frame(frame, sensor, rings=32, azimuths=3750):
+    """cfg4: one Velodyne-like sweep (rings x azimuths) of a plane + boxes scene, seeded per
+    (frame, sensor). Returns xyz, intensity in the sensor frame."""
+    rng = _rng(4001 + 97 * frame + sensor)
+    az = np.linspace(-np.pi, np.pi, azimuths, endpoint=False) + rng.uniform(0, 2 * np.pi / azimuths)
+    el = np.deg2rad(np.linspace(-25.0, 15.0, rings))
+    A, E = np.meshgrid(az, el)
+    d = np.stack([np.cos(E) * np.cos(A), np.cos(E) * np.sin(A), np.sin(E)], axis=-1).reshape(-1, 3)
+    h = 1.8
+    with np.errstate(divide="ignore"):
+        r_ground = np.where(d[:, 2] < -1e-3, -h / d[:, 2], np.inf)
+    r_wall = 18.0 + 4.0 * np.sin(3 * A.reshape(-1) + 0.1 * frame)
+    r = np.minimum(np.minimum(r_ground, r_wall), 60.0) + rng.normal(0, 0.02, len(d))
+    xyz = (d * r[:, None]).astype(np.float32)
+    inten = rng.uniform(0, 255, len(d)).astype(np.float32)
+    return xyz, inten
