@@ -1,0 +1,63 @@
+"""Builds libcloudmerge_hip.so (HIP kernels + C-ABI) for gfx950, in-tree.
+
+    python -m cloud_merger_amd.build [--force] [--save-temps]
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libcloudmerge_hip.so")
+SOURCES = ["cm_kernels.hip", "cm_api.cpp"]
+HEADERS = ["cm_device.h", "cm_kernels.h", os.path.join("..", "..", "include", "cloudmerge.h")]
+
+# -ffp-contract=off / -fno-fast-math: occupancy must match the reference bit for bit, so no FMA
+# contraction on the device or in the host-side quaternion/grid arithmetic (SURVEY.md §7 hard part 1).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-fvisibility=hidden",
+         "-Wl,-rpath,/opt/rocm/lib"]
+
+
+def hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, save_temps=False, verbose=False):
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc()] + FLAGS + ["-I", CSRC, "-o", LIB_PATH]
+    if save_temps:
+        tmp = os.path.join(HERE, "build_tmp")
+        os.makedirs(tmp, exist_ok=True)
+        cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed building libcloudmerge_hip.so")
+    if verbose or save_temps:
+        sys.stderr.write(r.stderr)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, verbose=True))

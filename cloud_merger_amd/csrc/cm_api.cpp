@@ -1,0 +1,650 @@
+// cm_api.cpp — host side of the C-ABI declared in include/cloudmerge.h.
+//
+// Owns the HBM layout and the launch sequence; no arithmetic on points happens here. There is no
+// CPU fallback of any kind: without a gfx950 device cm_create fails.
+//
+// HBM layout per context (N = padded point capacity, multiples of CM_TILE per sensor):
+//   sensor slots      raw PointCloud2 payloads as submitted (or caller-owned device pointers)
+//   keys_a/b, vals_a/b  4 x N x u32   radix ping-pong: voxel index, padded point index
+//   hist              256 x (N/4096) u32   per-tile digit counts -> per-tile global offsets
+//   seg_counts        N/2048 u32      kept voxels per sorted tile -> output offsets
+//   out               N x 16 B        centroids x,y,z,intensity (ascending voxel index = PCL order)
+//   out_key/out_cnt   N x u32 each    only with CM_FLAG_OCCUPANCY
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/cloudmerge.h"
+#include "cm_device.h"
+#include "cm_kernels.h"
+
+namespace {
+
+struct Slot {
+    std::mutex mu;
+    void* dbuf = nullptr;            // owned HBM buffer (host submits)
+    size_t dcap = 0;
+    const void* dptr = nullptr;      // active payload: dbuf or a caller-owned device pointer
+    uint32_t n = 0, step = 0, ox = 0, oy = 0, oz = 0, oi = 0;
+    bool has_data = false, fresh = false;
+    float m[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    hipStream_t copy_stream = nullptr;
+};
+
+}  // namespace
+
+struct cm_ctx {
+    int device = 0;
+    uint32_t flags = 0, max_sensors = 0;
+    uint64_t max_points = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    Slot slots[CM_MAX_SENSORS];
+
+    uint32_t cap_padded = 0, cap_tiles = 0, cap_seg_tiles = 0;
+    uint32_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr;
+    uint32_t *hist = nullptr, *totals = nullptr, *seg_counts = nullptr;
+    uint32_t *out_key = nullptr, *out_cnt = nullptr, *merged_total = nullptr;
+    void* out = nullptr;
+    void* merged = nullptr;
+    CmFrameDev* d_frame = nullptr;
+    CmFrameDev frame_uploaded;
+    bool frame_uploaded_valid = false;
+    CmFrameState* d_state[2] = {nullptr, nullptr};
+    int cur = 0;
+    CmFrameState* h_state = nullptr;     // pinned
+    hipEvent_t ev_done = nullptr;
+
+    std::mutex merge_mu;
+    std::atomic<bool> in_flight{false};
+    bool pending = false;                // an enqueued frame has not been waited for
+    bool pending_trivial = false;        // ... and it had no kernels (nothing submitted)
+    CmFrameDev frame;                    // descriptor of the last enqueued frame
+    bool from_crop = false;
+    uint64_t n_in = 0;
+    uint32_t n_sensors_used = 0;
+    cm_result result;
+    bool have_result = false;
+    bool out_is_merged = false;
+
+    std::vector<hipEvent_t> prof_ev;
+    std::vector<std::string> prof_names;
+    size_t prof_used = 0;
+    cm_stage_times stage_times;
+
+    std::string err;
+};
+
+namespace {
+
+const char* k_status_names(int s) {
+    switch (s) {
+        case CM_OK: return "CM_OK";
+        case CM_EMPTY_INPUT: return "CM_EMPTY_INPUT";
+        case CM_GRID_OVERFLOW: return "CM_GRID_OVERFLOW";
+        case CM_NOT_READY: return "CM_NOT_READY";
+        case CM_BAD_ARG: return "CM_BAD_ARG";
+        case CM_HIP_ERROR: return "CM_HIP_ERROR";
+        case CM_NO_DEVICE: return "CM_NO_DEVICE";
+        case CM_CAPACITY: return "CM_CAPACITY";
+        case CM_INTERNAL: return "CM_INTERNAL";
+        default: return "CM_UNKNOWN";
+    }
+}
+
+int fail(cm_ctx* c, int code, const std::string& what) {
+    if (c) c->err = what;
+    return code;
+}
+
+#define HIP_TRY(c, call)                                                                        \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            return fail((c), CM_HIP_ERROR, std::string(#call) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+// Eigen::Quaternionf(w,x,y,z).toRotationMatrix() in fp32, tf doubles rounded per component
+// (reference call site pc_preprocessing_main.cpp:320-322).
+void quat_to_rows(const double q[4], const double t[3], float m[12]) {
+    const float x = static_cast<float>(q[0]), y = static_cast<float>(q[1]);
+    const float z = static_cast<float>(q[2]), w = static_cast<float>(q[3]);
+    const float tx = 2.0f * x, ty = 2.0f * y, tz = 2.0f * z;
+    const float twx = tx * w, twy = ty * w, twz = tz * w;
+    const float txx = tx * x, txy = ty * x, txz = tz * x;
+    const float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    m[0] = 1.0f - (tyy + tzz); m[1] = txy - twz;          m[2] = txz + twy;           m[3] = static_cast<float>(t[0]);
+    m[4] = txy + twz;          m[5] = 1.0f - (txx + tzz); m[6] = tyz - twx;           m[7] = static_cast<float>(t[1]);
+    m[8] = txz - twy;          m[9] = tyz + twx;          m[10] = 1.0f - (txx + tyy); m[11] = static_cast<float>(t[2]);
+}
+
+// Host copy of k_bounds' guard for the crop box: true when the box itself fits PCL's int32 index,
+// in which case the data min/max pass can be skipped (box-relative indices give the same
+// occupancy and the same order). Also returns the key width.
+bool crop_box_grid(const cm_params& p, const float inv[3], uint32_t* key_bits) {
+    long long d[3];
+    unsigned long long cells = 1;
+    for (int a = 0; a < 3; ++a) {
+        const float ext = (p.crop_max[a] - p.crop_min[a]) * inv[a];
+        if (!(ext < 2147483648.0f) || ext < 0.0f) return false;
+        d[a] = static_cast<long long>(ext) + 1;
+        const int lo = static_cast<int>(std::floor(p.crop_min[a] * inv[a]));
+        const int hi = static_cast<int>(std::floor(p.crop_max[a] * inv[a]));
+        if (hi < lo) return false;
+        cells *= static_cast<unsigned long long>(hi - lo + 1);
+    }
+    if (d[0] * d[1] * d[2] > 2147483647LL || cells > 0xFFFFFFFFull) return false;
+    uint32_t bits = 1;
+    while (bits < 32 && (cells - 1) >> bits) ++bits;
+    *key_bits = bits;
+    return true;
+}
+
+void prof_mark(cm_ctx* c, const char* name) {
+    if (!(c->flags & CM_FLAG_PROFILE)) return;
+    if (c->prof_used >= c->prof_ev.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        c->prof_ev.push_back(e);
+        c->prof_names.emplace_back();
+    }
+    c->prof_names[c->prof_used] = name;
+    hipEventRecord(c->prof_ev[c->prof_used], c->stream);
+    ++c->prof_used;
+}
+
+void free_all(cm_ctx* c) {
+    auto F = [](void* p) { if (p) (void)hipFree(p); };
+    F(c->keys_a); F(c->keys_b); F(c->vals_a); F(c->vals_b); F(c->hist); F(c->totals);
+    F(c->seg_counts); F(c->out_key); F(c->out_cnt); F(c->merged_total); F(c->out); F(c->merged);
+    F(c->d_frame); F(c->d_state[0]); F(c->d_state[1]);
+    if (c->h_state) (void)hipHostFree(c->h_state);
+    for (auto& s : c->slots) {
+        F(s.dbuf);
+        if (s.copy_stream) (void)hipStreamDestroy(s.copy_stream);
+    }
+    for (auto e : c->prof_ev) (void)hipEventDestroy(e);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+}
+
+int set_slot_cloud(cm_ctx* c, uint32_t sensor, const void* data, bool on_device, uint32_t n,
+                   uint32_t step, uint32_t ox, uint32_t oy, uint32_t oz, uint32_t oi) {
+    if (!c) return CM_BAD_ARG;
+    if (sensor >= c->max_sensors) return fail(c, CM_BAD_ARG, "sensor index out of range");
+    if (n && !data) return fail(c, CM_BAD_ARG, "null payload");
+    const uint32_t need = (oi == CM_NO_FIELD) ? 0 : oi + 4;
+    if (n && (step < 12 || ox + 4 > step || oy + 4 > step || oz + 4 > step || need > step))
+        return fail(c, CM_BAD_ARG, "field offsets do not fit point_step");
+    if (n > c->max_points) return fail(c, CM_CAPACITY, "cloud larger than cm_limits.max_points_total");
+    HIP_TRY(c, hipSetDevice(c->device));
+    Slot& s = c->slots[sensor];
+    std::lock_guard<std::mutex> lk(s.mu);
+    if (s.fresh && !(c->flags & CM_FLAG_LATEST_WINS)) return CM_OK;   // first since last fuse wins
+    if (c->in_flight.load()) HIP_TRY(c, hipEventSynchronize(c->ev_done));
+    const size_t bytes = static_cast<size_t>(n) * step;
+    if (on_device) {
+        s.dptr = data;
+    } else {
+        if (bytes > s.dcap) {
+            if (s.dbuf) HIP_TRY(c, hipFree(s.dbuf));
+            s.dbuf = nullptr; s.dcap = 0;
+            const size_t cap = bytes + bytes / 4 + 256;
+            HIP_TRY(c, hipMalloc(&s.dbuf, cap));
+            s.dcap = cap;
+        }
+        if (bytes) {
+            HIP_TRY(c, hipMemcpyAsync(s.dbuf, data, bytes, hipMemcpyHostToDevice, s.copy_stream));
+            HIP_TRY(c, hipStreamSynchronize(s.copy_stream));
+        }
+        s.dptr = s.dbuf;
+    }
+    s.n = n; s.step = step; s.ox = ox; s.oy = oy; s.oz = oz; s.oi = oi;
+    s.has_data = true;
+    s.fresh = true;
+    return CM_OK;
+}
+
+// Builds the frame descriptor and enqueues every kernel of the frame on c->stream.
+int enqueue(cm_ctx* c, const cm_params* p) {
+    if (!c || !p) return CM_BAD_ARG;
+    for (int a = 0; a < 3; ++a)
+        if (!(p->leaf[a] > 0.0f) || !std::isfinite(p->leaf[a])) return fail(c, CM_BAD_ARG, "leaf must be > 0");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->pending) return fail(c, CM_BAD_ARG, "previous frame not waited for (cm_wait)");
+
+    std::vector<std::unique_lock<std::mutex>> locks;
+    for (uint32_t s = 0; s < c->max_sensors; ++s) locks.emplace_back(c->slots[s].mu);
+
+    // Frame assembly policy (pc_preprocessing_main.cpp:134-157).
+    uint32_t have = 0, fresh = 0;
+    for (uint32_t s = 0; s < c->max_sensors; ++s) {
+        if (c->slots[s].has_data) have |= 1u << s;
+        if (c->slots[s].fresh) fresh |= 1u << s;
+    }
+    const uint32_t required = p->required_sensor_mask ? p->required_sensor_mask : have;
+    if (have == 0 || (required & ~fresh) != 0) return CM_NOT_READY;
+
+    CmFrameDev& f = c->frame;
+    std::memset(&f, 0, sizeof f);
+    uint32_t base = 0, k = 0;
+    uint64_t n_in = 0;
+    for (uint32_t s = 0; s < c->max_sensors; ++s) {
+        Slot& sl = c->slots[s];
+        if (!sl.has_data) continue;          // stale optional sensors ride along like :141
+        CmSensorDev& d = f.s[k++];
+        d.data = static_cast<const unsigned char*>(sl.dptr);
+        d.n = sl.n; d.base = base; d.point_step = sl.step;
+        d.off_x = sl.ox; d.off_y = sl.oy; d.off_z = sl.oz; d.off_i = sl.oi;
+        const bool al16 = (reinterpret_cast<uintptr_t>(sl.dptr) & 15u) == 0;
+        if (al16 && sl.step == 16 && sl.ox == 0 && sl.oy == 4 && sl.oz == 8 && sl.oi == 12) d.layout = CM_LAYOUT_XYZI16;
+        else if (al16 && sl.step == 32 && sl.ox == 0 && sl.oy == 4 && sl.oz == 8 && sl.oi == 16) d.layout = CM_LAYOUT_PCL32;
+        else d.layout = CM_LAYOUT_GENERIC;
+        std::memcpy(d.m, sl.m, sizeof d.m);
+        n_in += sl.n;
+        const uint64_t nb = static_cast<uint64_t>(base) + round_up(sl.n, CM_TILE);
+        if (nb > c->cap_padded) return fail(c, CM_CAPACITY, "frame exceeds cm_limits.max_points_total");
+        base = static_cast<uint32_t>(nb);
+    }
+    f.n_sensors = k;
+    f.n_padded = base;
+    f.n_tiles = base / CM_TILE;
+    f.crop_enable = p->crop_enable ? 1u : 0u;
+    for (int a = 0; a < 3; ++a) {
+        f.crop_min[a] = p->crop_min[a];
+        f.crop_max[a] = p->crop_max[a];
+        f.inv_leaf[a] = 1.0f / p->leaf[a];          // Array4f::Ones() / leaf_size_: fp32 division
+    }
+    f.min_pts = p->min_points_per_voxel;
+    f.downsample_all = p->downsample_all_data ? 1u : 0u;
+    c->n_in = n_in;
+    c->n_sensors_used = k;
+    c->have_result = false;
+    c->out_is_merged = false;
+    c->prof_used = 0;
+
+    for (auto& sl : c->slots) sl.fresh = false;       // flag reset, :151-157
+
+    if (f.n_padded == 0) {                             // every submitted cloud is empty
+        c->pending = true;
+        c->pending_trivial = true;
+        return CM_OK;
+    }
+
+    hipStream_t st = c->stream;
+    if (!c->frame_uploaded_valid || std::memcmp(&f, &c->frame_uploaded, sizeof f) != 0) {
+        prof_mark(c, "k_setup");
+        cmk_setup(st, f, c->d_frame);
+        c->frame_uploaded = f;
+        c->frame_uploaded_valid = true;
+    }
+    CmFrameState* state = c->d_state[c->cur];
+    CmFrameState* state_next = c->d_state[c->cur ^ 1];
+    uint32_t key_bits = 0;
+    c->from_crop = f.crop_enable && crop_box_grid(*p, f.inv_leaf, &key_bits);
+    const uint32_t passes = c->from_crop ? (key_bits + CM_RADIX_BITS - 1) / CM_RADIX_BITS : CM_MAX_PASSES;
+    const uint32_t nt = f.n_tiles;
+    const uint32_t nseg = f.n_padded / CM_SEG_TILE;
+
+    if (!c->from_crop) { prof_mark(c, "k_minmax"); cmk_minmax(st, c->d_frame, state, nt); }
+    prof_mark(c, "k_bounds");
+    cmk_bounds(st, c->d_frame, state, c->from_crop ? 1 : 0);
+    prof_mark(c, "k_keys");
+    cmk_keys(st, c->d_frame, state, c->keys_a, c->hist, nt);
+    for (uint32_t pass = 0; pass < passes; ++pass) {
+        const bool even = (pass & 1u) == 0;
+        const uint32_t* kin = even ? c->keys_a : c->keys_b;
+        const uint32_t* vin = even ? c->vals_a : c->vals_b;
+        uint32_t* kout = even ? c->keys_b : c->keys_a;
+        uint32_t* vout = even ? c->vals_b : c->vals_a;
+        if (pass > 0) { prof_mark(c, "k_hist"); cmk_hist(st, state, kin, c->hist, pass, nt); }
+        prof_mark(c, "k_colscan");
+        cmk_colscan(st, state, c->hist, c->totals, pass, nt);
+        prof_mark(c, "k_scatter");
+        cmk_scatter(st, state, kin, vin, kout, vout, c->hist, c->totals, pass, nt, f.n_padded);
+    }
+    prof_mark(c, "k_seg_count");
+    cmk_seg_count(st, state, c->keys_a, c->keys_b, c->seg_counts, f.min_pts, nseg);
+    prof_mark(c, "k_finalize");
+    cmk_finalize(st, state, state_next, c->seg_counts, nseg);
+    prof_mark(c, "k_seg_reduce");
+    cmk_seg_reduce(st, c->d_frame, state, c->keys_a, c->vals_a, c->keys_b, c->vals_b, c->seg_counts,
+                   c->out, c->out_key, c->out_cnt, nseg);
+    prof_mark(c, "end");
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->h_state, state, sizeof(CmFrameState), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipEventRecord(c->ev_done, st));
+    c->cur ^= 1;
+    c->in_flight.store(true);
+    c->pending = true;
+    c->pending_trivial = false;
+    return CM_OK;
+}
+
+int wait_frame(cm_ctx* c, cm_result* res) {
+    if (!c) return CM_BAD_ARG;
+    if (!c->pending) return fail(c, CM_BAD_ARG, "no frame enqueued");
+    HIP_TRY(c, hipSetDevice(c->device));
+    cm_result r;
+    std::memset(&r, 0, sizeof r);
+    r.n_sensors = c->n_sensors_used;
+    r.n_in = c->n_in;
+    if (c->pending_trivial) {
+        r.status = CM_EMPTY_INPUT;
+    } else {
+        HIP_TRY(c, hipEventSynchronize(c->ev_done));
+        c->in_flight.store(false);
+        const CmFrameState& h = *c->h_state;
+        if (h.err) { c->pending = false; return fail(c, CM_INTERNAL, "device reported an internal error"); }
+        r.status = h.status;
+        r.bounds_from_crop = c->from_crop ? 1u : 0u;
+        for (int a = 0; a < 3; ++a) {
+            r.min_b[a] = h.min_b[a]; r.max_b[a] = h.max_b[a]; r.div_b[a] = h.div_b[a];
+            r.min_p[a] = h.min_p[a]; r.max_p[a] = h.max_p[a];
+        }
+        r.key_bits = h.key_bits;
+        r.sort_passes = h.n_passes;
+        if (h.status == CM_OK) {
+            r.n_merged = h.n_valid;
+            r.n_out = h.n_out;
+        } else if (h.status == CM_GRID_OVERFLOW) {
+            // PCL: "output = *input_" — hand back the merged cloud, unvoxelised (A.4 step 3).
+            cmk_merged(c->stream, c->d_frame, c->seg_counts, c->merged_total, c->out, c->frame.n_tiles);
+            uint32_t total = 0;
+            HIP_TRY(c, hipMemcpyAsync(&total, c->merged_total, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            r.n_merged = total;
+            r.n_out = total;
+            c->out_is_merged = true;
+        }
+        if (c->flags & CM_FLAG_PROFILE) {
+            cm_stage_times& t = c->stage_times;
+            std::memset(&t, 0, sizeof t);
+            const size_t n = c->prof_used ? c->prof_used - 1 : 0;
+            for (size_t i = 0; i < n && i < CM_MAX_STAGES; ++i) {
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, c->prof_ev[i], c->prof_ev[i + 1]);
+                std::snprintf(t.name[i], sizeof t.name[i], "%s", c->prof_names[i].c_str());
+                t.ms[i] = ms;
+                t.n_stages = static_cast<uint32_t>(i + 1);
+            }
+            if (c->prof_used >= 2)
+                (void)hipEventElapsedTime(&r.device_ms, c->prof_ev[0], c->prof_ev[c->prof_used - 1]);
+        }
+    }
+    c->pending = false;
+    c->result = r;
+    c->have_result = true;
+    if (res) *res = r;
+    return r.status;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cm_version(void) { return CM_VERSION; }
+const char* cm_status_string(int status) { return k_status_names(status); }
+const char* cm_last_error(cm_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int cm_create(cm_ctx** out, int device, const cm_limits* lim) {
+    if (!out || !lim) return CM_BAD_ARG;
+    *out = nullptr;
+    if (lim->max_sensors < 1 || lim->max_sensors > CM_MAX_SENSORS) return CM_BAD_ARG;
+    if (lim->max_points_total < 1 || lim->max_points_total >= (1ull << 30)) return CM_BAD_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CM_NO_DEVICE;
+    if (device < 0 || device >= ndev) return CM_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return CM_HIP_ERROR;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return CM_HIP_ERROR;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return CM_NO_DEVICE;   // kernels are gfx950-only
+
+    cm_ctx* c = new (std::nothrow) cm_ctx();
+    if (!c) return CM_INTERNAL;
+    c->device = device;
+    c->flags = lim->flags;
+    c->max_sensors = lim->max_sensors;
+    c->max_points = lim->max_points_total;
+    const uint64_t padded = static_cast<uint64_t>(round_up(static_cast<uint32_t>(lim->max_points_total), CM_TILE)) +
+                            static_cast<uint64_t>(lim->max_sensors) * CM_TILE;
+    c->cap_padded = static_cast<uint32_t>(padded);
+    c->cap_tiles = c->cap_padded / CM_TILE;
+    c->cap_seg_tiles = c->cap_padded / CM_SEG_TILE;
+
+    auto A = [&](void** p, size_t bytes) { return hipMalloc(p, bytes) == hipSuccess; };
+    const size_t n4 = static_cast<size_t>(c->cap_padded) * 4;
+    bool ok = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess;
+    c->stream = c->own_stream;
+    ok = ok && hipEventCreate(&c->ev_done) == hipSuccess;
+    ok = ok && A(reinterpret_cast<void**>(&c->keys_a), n4) && A(reinterpret_cast<void**>(&c->keys_b), n4);
+    ok = ok && A(reinterpret_cast<void**>(&c->vals_a), n4) && A(reinterpret_cast<void**>(&c->vals_b), n4);
+    ok = ok && A(reinterpret_cast<void**>(&c->hist), static_cast<size_t>(c->cap_tiles) * CM_RADIX * 4);
+    ok = ok && A(reinterpret_cast<void**>(&c->totals), CM_RADIX * 4);
+    ok = ok && A(reinterpret_cast<void**>(&c->seg_counts), static_cast<size_t>(c->cap_seg_tiles + c->cap_tiles) * 4);
+    ok = ok && A(reinterpret_cast<void**>(&c->merged_total), 256);
+    ok = ok && A(&c->out, static_cast<size_t>(c->cap_padded) * 16);
+    if (c->flags & CM_FLAG_OCCUPANCY)
+        ok = ok && A(reinterpret_cast<void**>(&c->out_key), n4) && A(reinterpret_cast<void**>(&c->out_cnt), n4);
+    ok = ok && A(reinterpret_cast<void**>(&c->d_frame), sizeof(CmFrameDev));
+    ok = ok && A(reinterpret_cast<void**>(&c->d_state[0]), sizeof(CmFrameState));
+    ok = ok && A(reinterpret_cast<void**>(&c->d_state[1]), sizeof(CmFrameState));
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_state), sizeof(CmFrameState), hipHostMallocDefault) == hipSuccess;
+    for (uint32_t s = 0; ok && s < c->max_sensors; ++s)
+        ok = hipStreamCreateWithFlags(&c->slots[s].copy_stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipMemset(c->d_state[0], 0, sizeof(CmFrameState)) == hipSuccess;
+    ok = ok && hipMemset(c->d_state[1], 0, sizeof(CmFrameState)) == hipSuccess;
+    ok = ok && hipDeviceSynchronize() == hipSuccess;
+    if (!ok) {
+        free_all(c);
+        delete c;
+        return CM_HIP_ERROR;
+    }
+    std::memset(&c->result, 0, sizeof c->result);
+    std::memset(&c->stage_times, 0, sizeof c->stage_times);
+    *out = c;
+    return CM_OK;
+}
+
+int cm_destroy(cm_ctx* c) {
+    if (!c) return CM_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    free_all(c);
+    delete c;
+    return CM_OK;
+}
+
+int cm_set_stream(cm_ctx* c, void* hip_stream) {
+    if (!c) return CM_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->merge_mu);
+    if (c->pending) return fail(c, CM_BAD_ARG, "cannot change stream with a frame in flight");
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return CM_OK;
+}
+
+int cm_set_sensor_transform(cm_ctx* c, uint32_t sensor, const double q[4], const double t[3]) {
+    if (!c || !q || !t) return CM_BAD_ARG;
+    if (sensor >= c->max_sensors) return fail(c, CM_BAD_ARG, "sensor index out of range");
+    float m[12];
+    quat_to_rows(q, t, m);
+    std::lock_guard<std::mutex> lk(c->slots[sensor].mu);
+    std::memcpy(c->slots[sensor].m, m, sizeof m);
+    return CM_OK;
+}
+
+int cm_set_sensor_matrix(cm_ctx* c, uint32_t sensor, const float m[12]) {
+    if (!c || !m) return CM_BAD_ARG;
+    if (sensor >= c->max_sensors) return fail(c, CM_BAD_ARG, "sensor index out of range");
+    std::lock_guard<std::mutex> lk(c->slots[sensor].mu);
+    std::memcpy(c->slots[sensor].m, m, 12 * sizeof(float));
+    return CM_OK;
+}
+
+int cm_get_sensor_matrix(cm_ctx* c, uint32_t sensor, float m[12]) {
+    if (!c || !m) return CM_BAD_ARG;
+    if (sensor >= c->max_sensors) return fail(c, CM_BAD_ARG, "sensor index out of range");
+    std::lock_guard<std::mutex> lk(c->slots[sensor].mu);
+    std::memcpy(m, c->slots[sensor].m, 12 * sizeof(float));
+    return CM_OK;
+}
+
+int cm_submit_cloud(cm_ctx* c, uint32_t sensor, const void* host_data, uint32_t n, uint32_t point_step,
+                    uint32_t off_x, uint32_t off_y, uint32_t off_z, uint32_t off_i) {
+    return set_slot_cloud(c, sensor, host_data, false, n, point_step, off_x, off_y, off_z, off_i);
+}
+
+int cm_submit_cloud_device(cm_ctx* c, uint32_t sensor, const void* dev_data, uint32_t n, uint32_t point_step,
+                           uint32_t off_x, uint32_t off_y, uint32_t off_z, uint32_t off_i) {
+    return set_slot_cloud(c, sensor, dev_data, true, n, point_step, off_x, off_y, off_z, off_i);
+}
+
+int cm_clear_sensor(cm_ctx* c, uint32_t sensor) {
+    if (!c) return CM_BAD_ARG;
+    if (sensor >= c->max_sensors) return fail(c, CM_BAD_ARG, "sensor index out of range");
+    std::lock_guard<std::mutex> lk(c->slots[sensor].mu);
+    c->slots[sensor].has_data = false;
+    c->slots[sensor].fresh = false;
+    c->slots[sensor].n = 0;
+    return CM_OK;
+}
+
+int cm_merge_voxelize_async(cm_ctx* c, const cm_params* p) {
+    if (!c) return CM_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->merge_mu);
+    return enqueue(c, p);
+}
+
+int cm_wait(cm_ctx* c, cm_result* res) {
+    if (!c) return CM_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->merge_mu);
+    return wait_frame(c, res);
+}
+
+int cm_merge_voxelize(cm_ctx* c, const cm_params* p, cm_result* res) {
+    if (!c) return CM_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->merge_mu);
+    const int e = enqueue(c, p);
+    if (e != CM_OK) {
+        if (res) { std::memset(res, 0, sizeof *res); res->status = e; }
+        return e;
+    }
+    return wait_frame(c, res);
+}
+
+int cm_result_device(cm_ctx* c, const void** dev_ptr, uint64_t* n_points) {
+    if (!c || !dev_ptr || !n_points) return CM_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->merge_mu);
+    if (!c->have_result) return fail(c, CM_BAD_ARG, "no result");
+    *dev_ptr = c->out;
+    *n_points = c->result.n_out;
+    return CM_OK;
+}
+
+int cm_result_copy(cm_ctx* c, void* host_dst, uint64_t capacity_points, uint32_t step_out) {
+    if (!c) return CM_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->merge_mu);
+    if (!c->have_result) return fail(c, CM_BAD_ARG, "no result");
+    if (step_out == 0) step_out = 16;
+    if (step_out != 16 && step_out != 32) return fail(c, CM_BAD_ARG, "point_step_out must be 16 or 32");
+    const uint64_t n = c->result.n_out;
+    if (n > capacity_points) return fail(c, CM_CAPACITY, "destination too small");
+    if (n == 0) return CM_OK;
+    if (!host_dst) return CM_BAD_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (step_out == 16) {
+        HIP_TRY(c, hipMemcpyAsync(host_dst, c->out, n * 16, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return CM_OK;
+    }
+    std::vector<float> tmp(n * 4);
+    HIP_TRY(c, hipMemcpyAsync(tmp.data(), c->out, n * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    float* d = static_cast<float*>(host_dst);     // pcl::PointXYZI image (A.0)
+    for (uint64_t i = 0; i < n; ++i) {
+        d[8 * i + 0] = tmp[4 * i + 0]; d[8 * i + 1] = tmp[4 * i + 1]; d[8 * i + 2] = tmp[4 * i + 2];
+        d[8 * i + 3] = 1.0f; d[8 * i + 4] = tmp[4 * i + 3];
+        d[8 * i + 5] = d[8 * i + 6] = d[8 * i + 7] = 0.0f;
+    }
+    return CM_OK;
+}
+
+int cm_result_copy_cells(cm_ctx* c, int32_t* ijk, uint32_t* counts, uint64_t capacity) {
+    if (!c) return CM_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->merge_mu);
+    if (!c->have_result) return fail(c, CM_BAD_ARG, "no result");
+    if (!(c->flags & CM_FLAG_OCCUPANCY)) return fail(c, CM_BAD_ARG, "context created without CM_FLAG_OCCUPANCY");
+    if (c->result.status != CM_OK) return fail(c, CM_BAD_ARG, "last frame has no voxel grid");
+    const uint64_t n = c->result.n_out;
+    if (n > capacity) return fail(c, CM_CAPACITY, "destination too small");
+    if (n == 0) return CM_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (counts) HIP_TRY(c, hipMemcpyAsync(counts, c->out_cnt, n * 4, hipMemcpyDeviceToHost, c->stream));
+    std::vector<uint32_t> keys;
+    if (ijk) {
+        keys.resize(n);
+        HIP_TRY(c, hipMemcpyAsync(keys.data(), c->out_key, n * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (ijk) {
+        const cm_result& r = c->result;
+        const uint32_t d0 = static_cast<uint32_t>(r.div_b[0]), d1 = static_cast<uint32_t>(r.div_b[1]);
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint32_t k = keys[i];
+            ijk[3 * i + 0] = static_cast<int32_t>(k % d0) + r.min_b[0];
+            ijk[3 * i + 1] = static_cast<int32_t>((k / d0) % d1) + r.min_b[1];
+            ijk[3 * i + 2] = static_cast<int32_t>(k / (d0 * d1)) + r.min_b[2];
+        }
+    }
+    return CM_OK;
+}
+
+int cm_merged_copy(cm_ctx* c, void* host_dst, uint64_t capacity, uint64_t* n_points) {
+    if (!c || !n_points) return CM_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->merge_mu);
+    if (!c->have_result) return fail(c, CM_BAD_ARG, "no result");
+    *n_points = 0;
+    if (c->frame.n_padded == 0) return CM_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->merged) HIP_TRY(c, hipMalloc(&c->merged, static_cast<size_t>(c->cap_padded) * 16));
+    // seg_counts holds this frame's output offsets in its first cap_seg_tiles words; use the tail.
+    uint32_t* counts = c->seg_counts + c->cap_seg_tiles;
+    cmk_merged(c->stream, c->d_frame, counts, c->merged_total, c->merged, c->frame.n_tiles);
+    uint32_t total = 0;
+    HIP_TRY(c, hipMemcpyAsync(&total, c->merged_total, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *n_points = total;
+    if (total > capacity) return fail(c, CM_CAPACITY, "destination too small");
+    if (total && host_dst) {
+        HIP_TRY(c, hipMemcpyAsync(host_dst, c->merged, static_cast<size_t>(total) * 16, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return CM_OK;
+}
+
+int cm_get_stage_times(cm_ctx* c, cm_stage_times* out) {
+    if (!c || !out) return CM_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->merge_mu);
+    if (!(c->flags & CM_FLAG_PROFILE)) return fail(c, CM_BAD_ARG, "context created without CM_FLAG_PROFILE");
+    *out = c->stage_times;
+    return CM_OK;
+}
+
+int cm_host_alloc(void** ptr, size_t bytes) {
+    if (!ptr) return CM_BAD_ARG;
+    return hipHostMalloc(ptr, bytes, hipHostMallocDefault) == hipSuccess ? CM_OK : CM_HIP_ERROR;
+}
+
+int cm_host_free(void* ptr) {
+    return hipHostFree(ptr) == hipSuccess ? CM_OK : CM_HIP_ERROR;
+}
+
+}  // extern "C"

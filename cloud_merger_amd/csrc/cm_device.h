@@ -1,0 +1,68 @@
+// cm_device.h — structures shared by the host-side C-ABI (cm_api.cpp) and the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+
+#define CM_DEV_MAX_SENSORS 16
+
+// Tiling of the padded point index space: every sensor starts at a multiple of CM_TILE, so a tile
+// never straddles two sensors (wave-uniform transform) and the key kernel can emit the first radix
+// histogram per tile.
+#define CM_TILE 4096          // points per workgroup in the streaming and radix kernels
+#define CM_BLOCK 256          // threads per workgroup (4 wave64)
+#define CM_ITEMS 16           // CM_TILE / CM_BLOCK
+#define CM_WAVES 4
+#define CM_RADIX_BITS 8
+#define CM_RADIX 256
+#define CM_MAX_PASSES 4
+#define CM_INVALID_KEY 0xFFFFFFFFu
+
+#define CM_SEG_TILE 2048      // sorted items per workgroup in the centroid kernels
+#define CM_SEG_ITEMS 8
+
+// Point layouts the loaders special-case.
+#define CM_LAYOUT_XYZI16 0    // x,y,z,intensity @0,4,8,12, step 16, 16-B aligned: one dwordx4 load
+#define CM_LAYOUT_PCL32 1     // pcl::PointXYZI image, step 32, intensity @16: dwordx4 + dword
+#define CM_LAYOUT_GENERIC 2   // any step/offsets, possibly unaligned: four dword loads
+
+struct CmSensorDev {
+    const unsigned char* data;
+    uint32_t n;               // points in the cloud
+    uint32_t base;            // first padded global index (multiple of CM_TILE)
+    uint32_t point_step;
+    uint32_t off_x, off_y, off_z, off_i;   // off_i == 0xFFFFFFFF: no intensity
+    uint32_t layout;
+    float m[12];              // row-major 3x4 [R|t]
+};
+
+struct CmFrameDev {
+    CmSensorDev s[CM_DEV_MAX_SENSORS];
+    uint32_t n_sensors;
+    uint32_t n_padded;        // size of the padded index space (multiple of CM_TILE)
+    uint32_t n_tiles;         // n_padded / CM_TILE
+    uint32_t crop_enable;
+    float crop_min[3];
+    float crop_max[3];
+    float inv_leaf[3];        // 1.0f / leaf, computed once on the host in fp32
+    uint32_t min_pts;
+    uint32_t downsample_all;
+};
+
+// Per-frame device state, zeroed before the first kernel of a frame.
+struct CmFrameState {
+    uint32_t mm[6];           // [0..2]: max over ~enc(x|y|z) (i.e. min), [3..5]: max over enc
+    uint32_t n_valid_k0;      // valid points counted by the min/max pass
+    int32_t status;           // cm_status of the frame (0 OK, 1 EMPTY, 2 OVERFLOW)
+    int32_t min_b[3], max_b[3], div_b[3];
+    float min_p[3], max_p[3];
+    uint32_t key_bits;
+    uint32_t n_passes;
+    uint32_t n_valid;         // points that entered the sort (after pass 0)
+    uint32_t n_out;
+    uint32_t n_seg_tiles;
+    uint32_t err;
+};
+
+// Device status codes mirror cm_status.
+#define CM_DEV_OK 0
+#define CM_DEV_EMPTY 1
+#define CM_DEV_OVERFLOW 2

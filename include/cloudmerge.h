@@ -1,0 +1,165 @@
+/*
+ * cloudmerge.h — C-ABI of the MI355X merge → voxel-grid library (libcloudmerge_hip.so).
+ *
+ * Drop-in boundary for ONE path of timspilak/cloud_merger: per-frame rigid transform of every
+ * sensor cloud into the common frame, optional AABB crop, concatenation across sensors and the
+ * PCL-VoxelGrid downsample.  The reference has no FFI layer for this path; its seam is the set of
+ * free functions and third-party calls cited per entry point below (all file:line references are
+ * into /root/reference/pcl_preprocessing/src/).  INTEGRATION.md shows the binding a maintainer of
+ * the reference node adds around these calls.
+ *
+ * Conventions: plain pointers and sizes only; every function returns a cm_status (never throws);
+ * the caller owns all host buffers; results live in the context until the next merge.
+ * Threading: cm_submit_cloud* may be called concurrently for DIFFERENT sensor slots (the
+ * reference's six subscriber threads, pc_preprocessing_main.cpp:513-525); cm_merge_voxelize* /
+ * cm_wait / cm_result_* from one consumer thread (the reference's 10 Hz main loop, :549-584).
+ * There is no CPU fallback: cm_create fails with CM_NO_DEVICE / CM_HIP_ERROR without a gfx950 GPU.
+ */
+#ifndef CLOUDMERGE_H
+#define CLOUDMERGE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define CM_API __attribute__((visibility("default")))
+#else
+#define CM_API
+#endif
+
+#define CM_VERSION 100            /* 0.1.0 */
+#define CM_MAX_SENSORS 16
+#define CM_NO_FIELD 0xFFFFFFFFu   /* off_i: the cloud has no intensity field (treated as 0) */
+
+typedef struct cm_ctx cm_ctx;
+
+typedef enum cm_status {
+    CM_OK = 0,
+    CM_EMPTY_INPUT = 1,    /* no point survived: PCL VoxelGrid returns width = height = 0 */
+    CM_GRID_OVERFLOW = 2,  /* PCL's int32 index guard tripped: output = merged input, unvoxelised */
+    CM_NOT_READY = 3,      /* a required sensor has no fresh cloud: the reference skips the tick (:134,:575) */
+    CM_BAD_ARG = -1,
+    CM_HIP_ERROR = -2,
+    CM_NO_DEVICE = -3,
+    CM_CAPACITY = -4,      /* more points than cm_limits allows */
+    CM_INTERNAL = -5
+} cm_status;
+
+/* cm_limits.flags */
+#define CM_FLAG_PROFILE        0x1u  /* record a HIP event pair around every kernel (cm_get_stage_times) */
+#define CM_FLAG_LATEST_WINS    0x2u  /* a newer cloud replaces an unconsumed one; default is the
+                                        reference's "first cloud since the last fuse wins" (:330,:356,...) */
+#define CM_FLAG_OCCUPANCY      0x4u  /* also keep (voxel index, point count) per output voxel for
+                                        cm_result_copy_cells (+8 B of HBM writes per voxel) */
+
+typedef struct cm_limits {
+    uint32_t max_sensors;          /* 1..CM_MAX_SENSORS */
+    uint32_t flags;
+    uint64_t max_points_total;     /* per frame, summed over sensors (< 2^30) */
+} cm_limits;
+
+/* Runtime form of the reference's compile-time constants (Parameter.h:27-35) and of the
+ * VoxelGrid settings at pc_preprocessing_main.cpp:173-175. */
+typedef struct cm_params {
+    float leaf[3];                 /* setLeafSize(v,v,v) :173; Parameter.h:28 */
+    uint32_t min_points_per_voxel; /* setMinimumPointsNumberPerVoxel :175; Parameter.h:27 */
+    int32_t downsample_all_data;   /* setDownsampleAllData(true) :174 */
+    int32_t crop_enable;           /* getROI :20-40 */
+    float crop_min[3];             /* x,y,z closed interval; Parameter.h:31-35 */
+    float crop_max[3];
+    uint32_t required_sensor_mask; /* bit s: sensor s must be fresh (:134); 0 = all submitted */
+    uint32_t _reserved;
+} cm_params;
+
+typedef struct cm_result {
+    int32_t status;                /* cm_status of the frame */
+    uint32_t n_sensors;            /* sensors that contributed */
+    uint64_t n_in;                 /* points submitted */
+    uint64_t n_merged;             /* after transform + crop (+ non-finite drop) */
+    uint64_t n_out;                /* voxels written (or n_merged on CM_GRID_OVERFLOW) */
+    int32_t min_b[3], max_b[3], div_b[3];   /* PCL's min_b_/max_b_/div_b_ (crop-box grid when
+                                               bounds_from_crop) */
+    float min_p[3], max_p[3];      /* getMinMax3D of the merged cloud (unset when bounds_from_crop) */
+    uint32_t bounds_from_crop;     /* 1: grid origin taken from the crop box (same occupancy and
+                                      order; the data min/max pass was skipped) */
+    uint32_t key_bits;             /* bits of the linear voxel index */
+    uint32_t sort_passes;          /* 8-bit radix passes run */
+    uint32_t _reserved;
+    float device_ms;               /* first kernel start -> last kernel end (CM_FLAG_PROFILE) */
+} cm_result;
+
+#define CM_MAX_STAGES 32
+typedef struct cm_stage_times {
+    uint32_t n_stages;
+    uint32_t _pad;
+    char name[CM_MAX_STAGES][24];  /* kernel name */
+    float ms[CM_MAX_STAGES];       /* duration of that launch in the last profiled frame */
+} cm_stage_times;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+/* Allocates the context, its stream and HBM work buffers on `device`. */
+CM_API int cm_create(cm_ctx** out, int device, const cm_limits* limits);
+CM_API int cm_destroy(cm_ctx* ctx);
+/* Run on a caller-owned hipStream_t (NULL: back to the context's own stream). */
+CM_API int cm_set_stream(cm_ctx* ctx, void* hip_stream);
+
+/* ---- static transforms: replaces tf::Transform(stf.getRotation(), stf.getOrigin()) (:320,:346,
+ * :371,:397,:424,:463) and the tf->Eigen conversion inside pcl_ros::transformPointCloud --------- */
+/* q/t are what tf::Transform::getRotation()/getOrigin() return (doubles). Converted on the host
+ * exactly as Eigen::Quaternionf::toRotationMatrix does in fp32. */
+CM_API int cm_set_sensor_transform(cm_ctx* ctx, uint32_t sensor, const double q_xyzw[4], const double t_xyz[3]);
+/* Row-major 3x4 fp32 [R|t], used verbatim. */
+CM_API int cm_set_sensor_matrix(cm_ctx* ctx, uint32_t sensor, const float m[12]);
+CM_API int cm_get_sensor_matrix(cm_ctx* ctx, uint32_t sensor, float m[12]);
+
+/* ---- ingest: replaces the subscriber callbacks' deserialise + transformPointCloud + getROI
+ * (:318-337 and siblings); the arithmetic itself runs inside cm_merge_voxelize ---------------- */
+/* Copies a sensor_msgs/PointCloud2 payload (n * point_step bytes, FLOAT32 fields at the given
+ * byte offsets) into the sensor's HBM slot. Returns after the caller's buffer may be reused. */
+CM_API int cm_submit_cloud(cm_ctx* ctx, uint32_t sensor, const void* host_data, uint32_t n,
+                    uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z, uint32_t off_i);
+/* Zero-copy variant: `dev_data` is already resident in HBM and stays valid until the merge that
+ * consumes it has completed. */
+CM_API int cm_submit_cloud_device(cm_ctx* ctx, uint32_t sensor, const void* dev_data, uint32_t n,
+                           uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z, uint32_t off_i);
+/* Forget a sensor's cloud (fresh or stale). */
+CM_API int cm_clear_sensor(cm_ctx* ctx, uint32_t sensor);
+
+/* ---- the path: replaces fusePointclouds (:131-160) + voxelgrid (:168-177) -------------------- */
+/* Synchronous: enqueue, wait, fill `res`. Returns res->status. */
+CM_API int cm_merge_voxelize(cm_ctx* ctx, const cm_params* p, cm_result* res);
+/* Enqueue only (no host wait); pair with cm_wait. Returns CM_OK / CM_NOT_READY / error. */
+CM_API int cm_merge_voxelize_async(cm_ctx* ctx, const cm_params* p);
+CM_API int cm_wait(cm_ctx* ctx, cm_result* res);
+
+/* ---- results: replaces pcl::toROSMsg of the voxel cloud (:215-216) --------------------------- */
+/* Copies the n_out output points to host memory: point_step_out 16 (x,y,z,intensity) or 32 (the
+ * pcl::PointXYZI image pcl::toROSMsg puts on the wire: x,y,z,1.0f,intensity,0,0,0). */
+CM_API int cm_result_copy(cm_ctx* ctx, void* host_dst, uint64_t capacity_points, uint32_t point_step_out);
+/* Device pointer of the compact 16-byte result records (valid until the next merge). */
+CM_API int cm_result_device(cm_ctx* ctx, const void** dev_ptr, uint64_t* n_points);
+/* Occupancy of the last CM_OK frame (needs CM_FLAG_OCCUPANCY): absolute voxel cell (i,j,k) and
+ * point count of every output voxel, in output order. Either pointer may be NULL. */
+CM_API int cm_result_copy_cells(cm_ctx* ctx, int32_t* ijk_host, uint32_t* counts_host, uint64_t capacity_voxels);
+/* The merged (transformed + cropped + concatenated) cloud of the last frame as 16-byte
+ * x,y,z,intensity records in sensor order — the reference's fused cloud (:137-142). */
+CM_API int cm_merged_copy(cm_ctx* ctx, void* host_dst, uint64_t capacity_points, uint64_t* n_points);
+
+/* ---- diagnostics --------------------------------------------------------------------------- */
+CM_API int cm_get_stage_times(cm_ctx* ctx, cm_stage_times* out);
+CM_API const char* cm_status_string(int status);
+CM_API const char* cm_last_error(cm_ctx* ctx);
+CM_API int cm_version(void);
+
+/* ---- host memory helpers (pinned staging for PointCloud2 payloads) --------------------------- */
+CM_API int cm_host_alloc(void** ptr, size_t bytes);
+CM_API int cm_host_free(void* ptr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLOUDMERGE_H */
