@@ -6,8 +6,9 @@
 // HBM layout per context (N = padded point capacity, multiples of CM_TILE per sensor):
 //   sensor slots      raw PointCloud2 payloads as submitted (or caller-owned device pointers)
 //   keys_a/b, vals_a/b  4 x N x u32   radix ping-pong: voxel index, padded point index
-//   hist              256 x (N/4096) u32   per-tile digit counts -> per-tile global offsets
-//   seg_counts        N/2048 u32      kept voxels per sorted tile -> output offsets
+//   hist              (N/4096) x 256 u32   digit counts per tile (one coalesced row each)
+//   grp               5 x (N/4096/32) x 256 u32   digit counts per group of 32 tiles, per pass
+//   sync_words        64 + N/2048 u32 tile ticket + published kept-voxel count per sorted tile
 //   out               N x 16 B        centroids x,y,z,intensity (ascending voxel index = PCL order)
 //   out_key/out_cnt   N x u32 each    only with CM_FLAG_OCCUPANCY
 #include <hip/hip_runtime.h>
@@ -49,7 +50,9 @@ struct cm_ctx {
 
     uint32_t cap_padded = 0, cap_tiles = 0, cap_seg_tiles = 0;
     uint32_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr;
-    uint32_t *hist = nullptr, *totals = nullptr, *seg_counts = nullptr;
+    uint32_t *hist = nullptr, *grp = nullptr, *totals = nullptr, *seg_counts = nullptr, *sync_words = nullptr;
+    uint32_t cap_groups = 0, frame_seq = 0;
+    float* partials = nullptr;
     uint32_t *out_key = nullptr, *out_cnt = nullptr, *merged_total = nullptr;
     void* out = nullptr;
     void* merged = nullptr;
@@ -157,14 +160,14 @@ void prof_mark(cm_ctx* c, const char* name) {
         c->prof_names.emplace_back();
     }
     c->prof_names[c->prof_used] = name;
-    hipEventRecord(c->prof_ev[c->prof_used], c->stream);
+    (void)hipEventRecord(c->prof_ev[c->prof_used], c->stream);
     ++c->prof_used;
 }
 
 void free_all(cm_ctx* c) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(c->keys_a); F(c->keys_b); F(c->vals_a); F(c->vals_b); F(c->hist); F(c->totals);
-    F(c->seg_counts); F(c->out_key); F(c->out_cnt); F(c->merged_total); F(c->out); F(c->merged);
+    F(c->seg_counts); F(c->sync_words); F(c->grp); F(c->partials); F(c->out_key); F(c->out_cnt); F(c->merged_total); F(c->out); F(c->merged);
     F(c->d_frame); F(c->d_state[0]); F(c->d_state[1]);
     if (c->h_state) (void)hipHostFree(c->h_state);
     for (auto& s : c->slots) {
@@ -294,30 +297,37 @@ int enqueue(cm_ctx* c, const cm_params* p) {
     const uint32_t nt = f.n_tiles;
     const uint32_t nseg = f.n_padded / CM_SEG_TILE;
 
-    if (!c->from_crop) { prof_mark(c, "k_minmax"); cmk_minmax(st, c->d_frame, state, nt); }
-    prof_mark(c, "k_bounds");
-    cmk_bounds(st, c->d_frame, state, c->from_crop ? 1 : 0);
+    const uint32_t n_partials = nt < CM_MINMAX_BLOCKS ? nt : CM_MINMAX_BLOCKS;
+    const uint32_t n_groups = (nt + CM_GROUP - 1) / CM_GROUP;
+    const uint32_t gw = n_groups * CM_RADIX;                     // words of one group-total array
+    // grp: [0],[1] pass-0 arrays (alternate per frame: k_keys accumulates into one and clears the
+    // other for the next frame), [2..4] passes 1..3 (cleared by k_keys, filled by k_hist).
+    const size_t gstride = static_cast<size_t>(c->cap_groups) * CM_RADIX;
+    uint32_t* grp0 = c->grp + gstride * (c->frame_seq & 1u);
+    uint32_t* grp0_next = c->grp + gstride * ((c->frame_seq & 1u) ^ 1u);
+    ++c->frame_seq;
+    const bool big = n_groups > CM_DIRECT_GROUPS;
+    if (!c->from_crop) { prof_mark(c, "k_minmax"); cmk_minmax(st, c->d_frame, c->partials, n_partials); }
     prof_mark(c, "k_keys");
-    cmk_keys(st, c->d_frame, state, c->keys_a, c->hist, nt);
+    cmk_keys(st, c->d_frame, state, c->keys_a, c->hist, grp0, grp0_next, c->grp + 2 * gstride, gw,
+             static_cast<uint32_t>(gstride), c->sync_words, c->partials, n_partials, c->from_crop ? 1 : 0, nt);
+    // NOTE: k_keys clears 3*gw words starting at grp[2]; passes 1..3 therefore live at stride gw.
     for (uint32_t pass = 0; pass < passes; ++pass) {
         const bool even = (pass & 1u) == 0;
         const uint32_t* kin = even ? c->keys_a : c->keys_b;
         const uint32_t* vin = even ? c->vals_a : c->vals_b;
         uint32_t* kout = even ? c->keys_b : c->keys_a;
         uint32_t* vout = even ? c->vals_b : c->vals_a;
-        if (pass > 0) { prof_mark(c, "k_hist"); cmk_hist(st, state, kin, c->hist, pass, nt); }
-        prof_mark(c, "k_colscan");
-        cmk_colscan(st, state, c->hist, c->totals, pass, nt);
+        uint32_t* grp = pass == 0 ? grp0 : c->grp + 2 * gstride + static_cast<size_t>(pass - 1) * gw;
+        if (pass > 0) { prof_mark(c, "k_hist"); cmk_hist(st, state, kin, c->hist, grp, pass, nt); }
+        if (big) { prof_mark(c, "k_gscan"); cmk_gscan(st, state, grp, c->totals, pass, n_groups); }
         prof_mark(c, "k_scatter");
-        cmk_scatter(st, state, kin, vin, kout, vout, c->hist, c->totals, pass, nt, f.n_padded);
+        cmk_scatter(st, state, kin, vin, kout, vout, c->hist, grp, big ? c->totals : nullptr, pass, nt,
+                    n_groups, f.n_padded);
     }
-    prof_mark(c, "k_seg_count");
-    cmk_seg_count(st, state, c->keys_a, c->keys_b, c->seg_counts, f.min_pts, nseg);
-    prof_mark(c, "k_finalize");
-    cmk_finalize(st, state, state_next, c->seg_counts, nseg);
     prof_mark(c, "k_seg_reduce");
-    cmk_seg_reduce(st, c->d_frame, state, c->keys_a, c->vals_a, c->keys_b, c->vals_b, c->seg_counts,
-                   c->out, c->out_key, c->out_cnt, nseg);
+    cmk_seg_reduce(st, c->d_frame, state, state_next, c->keys_a, c->vals_a, c->keys_b, c->vals_b,
+                   c->sync_words, c->out, c->out_key, c->out_cnt, nseg);
     prof_mark(c, "end");
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->h_state, state, sizeof(CmFrameState), hipMemcpyDeviceToHost, st));
@@ -428,6 +438,14 @@ int cm_create(cm_ctx** out, int device, const cm_limits* lim) {
     ok = ok && A(reinterpret_cast<void**>(&c->keys_a), n4) && A(reinterpret_cast<void**>(&c->keys_b), n4);
     ok = ok && A(reinterpret_cast<void**>(&c->vals_a), n4) && A(reinterpret_cast<void**>(&c->vals_b), n4);
     ok = ok && A(reinterpret_cast<void**>(&c->hist), static_cast<size_t>(c->cap_tiles) * CM_RADIX * 4);
+    c->cap_groups = (c->cap_tiles + CM_GROUP - 1) / CM_GROUP;
+    {
+        const size_t gbytes = static_cast<size_t>(c->cap_groups) * CM_RADIX * 4 * 5;
+        ok = ok && A(reinterpret_cast<void**>(&c->grp), gbytes);
+        ok = ok && hipMemset(c->grp, 0, gbytes) == hipSuccess;
+    }
+    ok = ok && A(reinterpret_cast<void**>(&c->sync_words), static_cast<size_t>(CM_SYNC_HEADER + c->cap_seg_tiles) * 4);
+    ok = ok && A(reinterpret_cast<void**>(&c->partials), CM_MINMAX_BLOCKS * 8 * sizeof(float));
     ok = ok && A(reinterpret_cast<void**>(&c->totals), CM_RADIX * 4);
     ok = ok && A(reinterpret_cast<void**>(&c->seg_counts), static_cast<size_t>(c->cap_seg_tiles + c->cap_tiles) * 4);
     ok = ok && A(reinterpret_cast<void**>(&c->merged_total), 256);

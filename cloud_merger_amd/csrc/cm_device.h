@@ -16,8 +16,14 @@
 #define CM_MAX_PASSES 4
 #define CM_INVALID_KEY 0xFFFFFFFFu
 
-#define CM_SEG_TILE 2048      // sorted items per workgroup in the centroid kernels
+#define CM_GROUP 32           // tiles per group total in the radix passes
+#define CM_DIRECT_GROUPS 64   // up to this many groups k_scatter sums the group totals itself
+
+#define CM_SEG_TILE 2048      // sorted items per workgroup in the centroid kernel
 #define CM_SEG_ITEMS 8
+#define CM_MINMAX_BLOCKS 512  // workgroups (= partial records) of the min/max pass
+#define CM_SYNC_HEADER 64     // sync_words: [0] centroid tile ticket,
+                              // [CM_SYNC_HEADER + t] published kept-voxel count of sorted tile t
 
 // Point layouts the loaders special-case.
 #define CM_LAYOUT_XYZI16 0    // x,y,z,intensity @0,4,8,12, step 16, 16-B aligned: one dwordx4 load
@@ -49,7 +55,7 @@ struct CmFrameDev {
 
 // Per-frame device state, zeroed before the first kernel of a frame.
 struct CmFrameState {
-    uint32_t mm[6];           // [0..2]: max over ~enc(x|y|z) (i.e. min), [3..5]: max over enc
+    uint32_t _unused[6];
     uint32_t n_valid_k0;      // valid points counted by the min/max pass
     int32_t status;           // cm_status of the frame (0 OK, 1 EMPTY, 2 OVERFLOW)
     int32_t min_b[3], max_b[3], div_b[3];

@@ -1,14 +1,15 @@
 // cm_kernels.hip — gfx950 kernels of the merge → voxel-grid path.
 //
 // Pipeline per frame (all on one stream, no host round trip):
-//   k_minmax     K0  transform + crop, fp32 min/max of the merged cloud (skipped when the crop box
-//                    already bounds the grid)                                  [HBM: 16 B/pt read]
-//   k_bounds     Kb  PCL's overflow guard, min_b/div_b, key width
-//   k_keys       K1  transform + crop + voxel key, first radix histogram      [16 B/pt r, 4 B/pt w]
-//   per 8-bit digit: k_hist (not for digit 0), k_colscan, k_scatter           [LDS-tiled LSD radix]
-//   k_seg_count  K3a kept voxels per tile of the sorted keys
-//   k_finalize   K3s tile offsets, n_out, status; zeroes the next frame's state
-//   k_seg_reduce K3b gather + wavefront segmented centroid reduction          [16 B/voxel write]
+//   k_minmax     K0  transform + crop, fp32 min/max of the merged cloud per workgroup (skipped
+//                    when the crop box already bounds the grid)               [HBM: 16 B/pt read]
+//   k_keys       K1  PCL's overflow guard and grid, transform + crop + voxel key, digit-0 counts
+//                    per tile and per group of tiles                          [16 B/pt r, 4 B/pt w]
+//   per 8-bit digit: k_hist (digits 1..3: counts per tile and per group), k_scatter (cross-tile
+//                    offsets summed in its prologue, stable LDS-tiled scatter); frames of more
+//                    than CM_DIRECT_GROUPS groups run k_gscan in between      [LDS-tiled LSD radix]
+//   k_seg_reduce K3  kept voxels per sorted tile (published), gather + wavefront segmented
+//                    centroid reduction, threshold, compaction                [16 B/voxel write]
 //
 // Arithmetic restates what the reference gets from pcl_ros::transformPointCloud
 // (pc_preprocessing_main.cpp:322), pcl::PassThrough in getROI (:20-40) and pcl::VoxelGrid (:171-176);
@@ -25,15 +26,6 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t enc_f32(float f) {       // order-preserving float -> uint
-    const uint32_t u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float dec_f32(uint32_t e) {
-    const uint32_t u = (e & 0x80000000u) ? (e & 0x7FFFFFFFu) : ~e;
-    return __uint_as_float(u);
-}
-
 struct Pt { float x, y, z, i; };
 
 __device__ __forceinline__ float load_f32_unaligned(const unsigned char* p) {
@@ -139,36 +131,59 @@ __global__ void k_setup(CmFrameDev f, CmFrameDev* __restrict__ dst) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K0: min/max of the transformed, cropped cloud (pcl::getMinMax3D, A.4 step 2)
+// Tile loader: the 16 points a thread owns in its tile (wave-striped), every load issued before
+// the first use. Slots past the end of the cloud read as NaN and are never valid.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(CM_BLOCK) void k_minmax(const CmFrameDev* __restrict__ fd,
-                                                     CmFrameState* __restrict__ st) {
-    __shared__ float s_red[CM_WAVES][6];
-    __shared__ uint32_t s_cnt[CM_WAVES];
-    const uint32_t tile = blockIdx.x;
-    const uint32_t s = sensor_of_tile(fd, tile);
-    const CmSensorDev& sd = fd->s[s];
-    const unsigned char* data = sd.data;
-    const uint32_t n = sd.n, layout = sd.layout, step = sd.point_step;
+template <int LAYOUT>
+__device__ __forceinline__ void load_tile_points(const CmSensorDev& sd, uint32_t first, Pt (&p)[CM_ITEMS]) {
+    const unsigned char* __restrict__ data = sd.data;
+    const uint32_t n = sd.n, step = sd.point_step;
     const uint32_t ox = sd.off_x, oy = sd.off_y, oz = sd.off_z, oi = sd.off_i;
-    float m[12];
+    const float nan = __uint_as_float(0x7FC00000u);
 #pragma unroll
-    for (int k = 0; k < 12; ++k) m[k] = sd.m[k];
-    const uint32_t crop = fd->crop_enable;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t first = tile * CM_TILE - sd.base + w * (64 * CM_ITEMS) + lane;
-
-    const float inf = __uint_as_float(0x7F800000u);
-    float mn0 = inf, mn1 = inf, mn2 = inf, mx0 = -inf, mx1 = -inf, mx2 = -inf;
-    uint32_t cnt = 0;
-#pragma unroll 4
     for (int r = 0; r < CM_ITEMS; ++r) {
         const uint32_t i = first + r * 64;
         if (i < n) {
-            const Pt p = load_point(data, layout, step, ox, oy, oz, oi, i);
-            const float x = xf_row(m[0], m[1], m[2], m[3], p.x, p.y, p.z);
-            const float y = xf_row(m[4], m[5], m[6], m[7], p.x, p.y, p.z);
-            const float z = xf_row(m[8], m[9], m[10], m[11], p.x, p.y, p.z);
+            p[r] = load_point(data, LAYOUT, step, ox, oy, oz, oi, i);
+        } else {
+            p[r].x = nan; p[r].y = nan; p[r].z = nan; p[r].i = 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ void load_tile(const CmSensorDev& sd, uint32_t first, Pt (&p)[CM_ITEMS]) {
+    if (sd.layout == CM_LAYOUT_XYZI16) load_tile_points<CM_LAYOUT_XYZI16>(sd, first, p);
+    else if (sd.layout == CM_LAYOUT_PCL32) load_tile_points<CM_LAYOUT_PCL32>(sd, first, p);
+    else load_tile_points<CM_LAYOUT_GENERIC>(sd, first, p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0: min/max of the transformed, cropped cloud (pcl::getMinMax3D, A.4 step 2). One record per
+// workgroup (min xyz, max xyz, valid count), no atomics; k_keys folds the records.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(CM_BLOCK) void k_minmax(const CmFrameDev* __restrict__ fd,
+                                                     float* __restrict__ partials) {
+    __shared__ float s_red[CM_WAVES][6];
+    __shared__ uint32_t s_cnt[CM_WAVES];
+    const uint32_t crop = fd->crop_enable;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float inf = __uint_as_float(0x7F800000u);
+    float mn0 = inf, mn1 = inf, mn2 = inf, mx0 = -inf, mx1 = -inf, mx2 = -inf;
+    uint32_t cnt = 0;
+    for (uint32_t tile = blockIdx.x; tile < fd->n_tiles; tile += gridDim.x) {
+        const uint32_t s = sensor_of_tile(fd, tile);
+        const CmSensorDev& sd = fd->s[s];
+        float m[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) m[k] = sd.m[k];
+        const uint32_t first = tile * CM_TILE - sd.base + w * (64 * CM_ITEMS) + lane;
+        Pt p[CM_ITEMS];
+        load_tile(sd, first, p);
+#pragma unroll
+        for (int r = 0; r < CM_ITEMS; ++r) {
+            const float x = xf_row(m[0], m[1], m[2], m[3], p[r].x, p[r].y, p[r].z);
+            const float y = xf_row(m[4], m[5], m[6], m[7], p[r].x, p[r].y, p[r].z);
+            const float z = xf_row(m[8], m[9], m[10], m[11], p[r].x, p[r].y, p[r].z);
             if (point_valid(x, y, z, crop, fd->crop_min, fd->crop_max)) {
                 mn0 = fminf(mn0, x); mx0 = fmaxf(mx0, x);
                 mn1 = fminf(mn1, y); mx1 = fmaxf(mx1, y);
@@ -190,157 +205,246 @@ __global__ __launch_bounds__(CM_BLOCK) void k_minmax(const CmFrameDev* __restric
         s_cnt[w] = cnt;
     }
     __syncthreads();
-    if (threadIdx.x < 6) {
+    if (threadIdx.x < 8) {                       // record: min xyz, max xyz, count, pad
         const int k = threadIdx.x;
-        float v = s_red[0][k];
-        for (int q = 1; q < CM_WAVES; ++q) v = (k < 3) ? fminf(v, s_red[q][k]) : fmaxf(v, s_red[q][k]);
-        const uint32_t total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-        if (total) {
-            const uint32_t e = enc_f32(v);
-            atomicMax(&st->mm[k], (k < 3) ? ~e : e);
-            if (k == 0) atomicAdd(&st->n_valid_k0, total);
+        float v = 0.f;
+        if (k < 6) {
+            v = s_red[0][k];
+            for (int q = 1; q < CM_WAVES; ++q) v = (k < 3) ? fminf(v, s_red[q][k]) : fmaxf(v, s_red[q][k]);
+        } else if (k == 6) {
+            v = __uint_as_float(s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]);
         }
+        partials[blockIdx.x * 8 + k] = v;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Kb: overflow guard, min_b/max_b/div_b, key width (A.4 steps 3-4). One thread.
+// Grid set-up: PCL's overflow guard, min_b/max_b/div_b, key width (A.4 steps 3-4). Evaluated by
+// every workgroup of k_keys from k_minmax's records (or the crop box); workgroup 0 records it.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_bounds(const CmFrameDev* __restrict__ fd, CmFrameState* __restrict__ st, int from_crop) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+struct Grid {
+    int status;
+    uint32_t n_valid_k0;
     float min_p[3], max_p[3];
+    int min_b[3], max_b[3], div_b[3];
+    uint32_t key_bits, n_passes;
+};
+
+__device__ __forceinline__ void compute_grid(const CmFrameDev* __restrict__ fd,
+                                             const float* __restrict__ partials, uint32_t n_partials,
+                                             int from_crop, float (*s_red)[8], Grid& g) {
+    g.status = CM_DEV_OK;
+    g.key_bits = 0; g.n_passes = 0; g.n_valid_k0 = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { g.min_b[a] = 0; g.max_b[a] = 0; g.div_b[a] = 1; g.min_p[a] = 0.f; g.max_p[a] = 0.f; }
     if (from_crop) {
-        for (int a = 0; a < 3; ++a) { min_p[a] = fd->crop_min[a]; max_p[a] = fd->crop_max[a]; }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { g.min_p[a] = fd->crop_min[a]; g.max_p[a] = fd->crop_max[a]; }
     } else {
-        if (st->n_valid_k0 == 0) { st->status = CM_DEV_EMPTY; return; }
-        for (int a = 0; a < 3; ++a) { min_p[a] = dec_f32(~st->mm[a]); max_p[a] = dec_f32(st->mm[3 + a]); }
+        // getMinMax3D: fold the per-workgroup records of k_minmax (min/max are exact and
+        // order-independent, so every workgroup gets the same answer).
+        const float inf = __uint_as_float(0x7F800000u);
+        float v[6] = {inf, inf, inf, -inf, -inf, -inf};
+        uint32_t cnt = 0;
+        for (uint32_t r = threadIdx.x; r < n_partials; r += CM_BLOCK) {
+            const float4 lo = *reinterpret_cast<const float4*>(partials + r * 8);
+            const float4 hi = *reinterpret_cast<const float4*>(partials + r * 8 + 4);
+            v[0] = fminf(v[0], lo.x); v[1] = fminf(v[1], lo.y); v[2] = fminf(v[2], lo.z);
+            v[3] = fmaxf(v[3], lo.w); v[4] = fmaxf(v[4], hi.x); v[5] = fmaxf(v[5], hi.y);
+            cnt += __float_as_uint(hi.z);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[k] = fminf(v[k], __shfl_xor(v[k], d));
+#pragma unroll
+            for (int k = 3; k < 6; ++k) v[k] = fmaxf(v[k], __shfl_xor(v[k], d));
+            cnt += __shfl_xor(cnt, d);
+        }
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s_red[w][k] = v[k];
+            s_red[w][6] = __uint_as_float(cnt);
+        }
+        __syncthreads();
+        cnt = 0;
+#pragma unroll
+        for (int q = 0; q < CM_WAVES; ++q) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[k] = (q == 0) ? s_red[0][k] : fminf(v[k], s_red[q][k]);
+#pragma unroll
+            for (int k = 3; k < 6; ++k) v[k] = (q == 0) ? s_red[0][k] : fmaxf(v[k], s_red[q][k]);
+            cnt += __float_as_uint(s_red[q][6]);
+        }
+        g.n_valid_k0 = cnt;
+        if (cnt == 0) { g.status = CM_DEV_EMPTY; return; }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { g.min_p[a] = v[a]; g.max_p[a] = v[3 + a]; }
     }
     long long d[3];
     bool overflow = false;
+#pragma unroll
     for (int a = 0; a < 3; ++a) {
-        st->min_p[a] = min_p[a];
-        st->max_p[a] = max_p[a];
-        const float ext = __fmul_rn(__fsub_rn(max_p[a], min_p[a]), fd->inv_leaf[a]);
+        const float ext = __fmul_rn(__fsub_rn(g.max_p[a], g.min_p[a]), fd->inv_leaf[a]);
         if (!(ext < 2147483648.0f)) { overflow = true; d[a] = 0; }
         else d[a] = static_cast<long long>(ext) + 1;       // truncation toward zero
     }
     if (!overflow && d[0] * d[1] * d[2] > 2147483647LL) overflow = true;
-    if (overflow) { st->status = CM_DEV_OVERFLOW; return; }
+    if (overflow) { g.status = CM_DEV_OVERFLOW; return; }
     unsigned long long cells = 1;
+#pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const int lo = static_cast<int>(floorf(__fmul_rn(min_p[a], fd->inv_leaf[a])));
-        const int hi = static_cast<int>(floorf(__fmul_rn(max_p[a], fd->inv_leaf[a])));
-        st->min_b[a] = lo; st->max_b[a] = hi; st->div_b[a] = hi - lo + 1;
+        const int lo = static_cast<int>(floorf(__fmul_rn(g.min_p[a], fd->inv_leaf[a])));
+        const int hi = static_cast<int>(floorf(__fmul_rn(g.max_p[a], fd->inv_leaf[a])));
+        g.min_b[a] = lo; g.max_b[a] = hi; g.div_b[a] = hi - lo + 1;
         cells *= static_cast<unsigned long long>(hi - lo + 1);
     }
     // div_b can exceed the guard's dx by one per axis; the 32-bit key still has to hold it.
-    if (cells > 0xFFFFFFFFull) { st->status = CM_DEV_OVERFLOW; return; }
+    if (cells > 0xFFFFFFFFull) { g.status = CM_DEV_OVERFLOW; return; }
     uint32_t bits = 1;
     while (bits < 32 && (cells - 1) >> bits) ++bits;
-    st->key_bits = bits;
-    st->n_passes = (bits + CM_RADIX_BITS - 1) / CM_RADIX_BITS;
+    g.key_bits = bits;
+    g.n_passes = (bits + CM_RADIX_BITS - 1) / CM_RADIX_BITS;
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: transform + crop + linear voxel index (A.4 step 5) + digit-0 histogram per tile.
-// Keys of cropped / non-finite / padding slots are CM_INVALID_KEY and never enter the sort.
+// K1: grid set-up + transform + crop + linear voxel index (A.4 step 5) + digit-0 counts of the
+// tile (one coalesced row) and of its group of CM_GROUP tiles. Keys of cropped / non-finite /
+// padding slots are CM_INVALID_KEY and never enter the sort. Also clears the ticket word, the
+// words the centroid kernel's workgroups publish through and the group totals of every pass.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(CM_BLOCK) void k_keys(const CmFrameDev* __restrict__ fd,
-                                                   const CmFrameState* __restrict__ st,
+                                                   CmFrameState* __restrict__ st,
                                                    uint32_t* __restrict__ keys,
-                                                   uint32_t* __restrict__ hist) {
+                                                   uint32_t* __restrict__ hist,
+                                                   uint32_t* __restrict__ grp_acc,
+                                                   uint32_t* __restrict__ grp_clear_a,
+                                                   uint32_t* __restrict__ grp_clear_b,
+                                                   uint32_t n_group_words, uint32_t n_clear_a_words,
+                                                   uint32_t* __restrict__ sync_words,
+                                                   const float* __restrict__ partials,
+                                                   uint32_t n_partials, int from_crop) {
     __shared__ uint32_t lh[CM_RADIX];
-    if (st->status != CM_DEV_OK) return;
+    __shared__ float s_red[CM_WAVES][8];
     const uint32_t tile = blockIdx.x;
+    if (threadIdx.x < CM_TILE / CM_SEG_TILE) sync_words[CM_SYNC_HEADER + tile * (CM_TILE / CM_SEG_TILE) + threadIdx.x] = 0;
+    if (tile == 0 && threadIdx.x < CM_SYNC_HEADER) sync_words[threadIdx.x] = 0;
+    // Clear the group totals of passes 1..3 (grp_clear_b, three arrays) and the pass-0 array the
+    // NEXT frame accumulates into (grp_clear_a); this frame's pass-0 array (grp_acc) was cleared
+    // by the previous frame.
+    for (uint32_t k = tile * CM_BLOCK + threadIdx.x; k < 3 * n_group_words; k += gridDim.x * CM_BLOCK)
+        grp_clear_b[k] = 0;
+    for (uint32_t k = tile * CM_BLOCK + threadIdx.x; k < n_clear_a_words; k += gridDim.x * CM_BLOCK)
+        grp_clear_a[k] = 0;                             // whole array: the next frame may be larger
+
+    Grid g;
+    compute_grid(fd, partials, n_partials, from_crop, s_red, g);
+    if (tile == 0 && threadIdx.x == 0) {
+        st->status = g.status;
+        st->n_valid_k0 = g.n_valid_k0;
+        for (int a = 0; a < 3; ++a) {
+            st->min_p[a] = g.min_p[a]; st->max_p[a] = g.max_p[a];
+            st->min_b[a] = g.min_b[a]; st->max_b[a] = g.max_b[a]; st->div_b[a] = g.div_b[a];
+        }
+        st->key_bits = g.key_bits;
+        st->n_passes = g.n_passes;
+    }
+    if (g.status != CM_DEV_OK) return;
+
     const uint32_t s = sensor_of_tile(fd, tile);
     const CmSensorDev& sd = fd->s[s];
-    const unsigned char* data = sd.data;
-    const uint32_t n = sd.n, layout = sd.layout, step = sd.point_step;
-    const uint32_t ox = sd.off_x, oy = sd.off_y, oz = sd.off_z, oi = sd.off_i;
     float m[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) m[k] = sd.m[k];
     const uint32_t crop = fd->crop_enable;
     const float inv0 = fd->inv_leaf[0], inv1 = fd->inv_leaf[1], inv2 = fd->inv_leaf[2];
-    const float fb0 = static_cast<float>(st->min_b[0]), fb1 = static_cast<float>(st->min_b[1]),
-                fb2 = static_cast<float>(st->min_b[2]);
-    const uint32_t mul1 = static_cast<uint32_t>(st->div_b[0]);
-    const uint32_t mul2 = mul1 * static_cast<uint32_t>(st->div_b[1]);
+    const float fb0 = static_cast<float>(g.min_b[0]), fb1 = static_cast<float>(g.min_b[1]),
+                fb2 = static_cast<float>(g.min_b[2]);
+    const uint32_t mul1 = static_cast<uint32_t>(g.div_b[0]);
+    const uint32_t mul2 = mul1 * static_cast<uint32_t>(g.div_b[1]);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t slot0 = tile * CM_TILE + w * (64 * CM_ITEMS) + lane;   // padded global index
     const uint32_t first = slot0 - sd.base;                                // index in the sensor cloud
 
+    Pt p[CM_ITEMS];
+    load_tile(sd, first, p);
     lh[threadIdx.x] = 0;
     __syncthreads();
-#pragma unroll 4
+#pragma unroll
     for (int r = 0; r < CM_ITEMS; ++r) {
-        const uint32_t i = first + r * 64;
         uint32_t key = CM_INVALID_KEY;
-        if (i < n) {
-            const Pt p = load_point(data, layout, step, ox, oy, oz, oi, i);
-            const float x = xf_row(m[0], m[1], m[2], m[3], p.x, p.y, p.z);
-            const float y = xf_row(m[4], m[5], m[6], m[7], p.x, p.y, p.z);
-            const float z = xf_row(m[8], m[9], m[10], m[11], p.x, p.y, p.z);
-            if (point_valid(x, y, z, crop, fd->crop_min, fd->crop_max)) {
-                const int c0 = static_cast<int>(__fsub_rn(floorf(__fmul_rn(x, inv0)), fb0));
-                const int c1 = static_cast<int>(__fsub_rn(floorf(__fmul_rn(y, inv1)), fb1));
-                const int c2 = static_cast<int>(__fsub_rn(floorf(__fmul_rn(z, inv2)), fb2));
-                key = static_cast<uint32_t>(c0) + static_cast<uint32_t>(c1) * mul1 +
-                      static_cast<uint32_t>(c2) * mul2;
-                atomicAdd(&lh[key & (CM_RADIX - 1)], 1u);
-            }
+        const float x = xf_row(m[0], m[1], m[2], m[3], p[r].x, p[r].y, p[r].z);
+        const float y = xf_row(m[4], m[5], m[6], m[7], p[r].x, p[r].y, p[r].z);
+        const float z = xf_row(m[8], m[9], m[10], m[11], p[r].x, p[r].y, p[r].z);
+        if (point_valid(x, y, z, crop, fd->crop_min, fd->crop_max)) {
+            const int c0 = static_cast<int>(__fsub_rn(floorf(__fmul_rn(x, inv0)), fb0));
+            const int c1 = static_cast<int>(__fsub_rn(floorf(__fmul_rn(y, inv1)), fb1));
+            const int c2 = static_cast<int>(__fsub_rn(floorf(__fmul_rn(z, inv2)), fb2));
+            key = static_cast<uint32_t>(c0) + static_cast<uint32_t>(c1) * mul1 +
+                  static_cast<uint32_t>(c2) * mul2;
+            atomicAdd(&lh[key & (CM_RADIX - 1)], 1u);
         }
         keys[slot0 + r * 64] = key;
     }
     __syncthreads();
-    hist[static_cast<size_t>(threadIdx.x) * fd->n_tiles + tile] = lh[threadIdx.x];
+    const uint32_t c = lh[threadIdx.x];
+    hist[static_cast<size_t>(tile) * CM_RADIX + threadIdx.x] = c;
+    if (c) atomicAdd(&grp_acc[static_cast<size_t>(tile / CM_GROUP) * CM_RADIX + threadIdx.x], c);
 }
 
 // ------------------------------------------------------------------------------------------------
 // LSD radix sort of (key, point index): one 8-bit digit per pass, 4096-item tiles in LDS.
 // ------------------------------------------------------------------------------------------------
-// Per-tile digit histogram for passes >= 1 (the compacted, partially sorted pairs).
+// Digit counts of every tile (one coalesced 1 KB row) and of every group of CM_GROUP tiles for
+// passes >= 1 (the compacted, partially sorted pairs).
 __global__ __launch_bounds__(CM_BLOCK) void k_hist(const CmFrameState* __restrict__ st,
                                                    const uint32_t* __restrict__ keys,
                                                    uint32_t* __restrict__ hist,
-                                                   uint32_t pass, uint32_t n_tiles) {
+                                                   uint32_t* __restrict__ grp, uint32_t pass) {
     __shared__ uint32_t lh[CM_RADIX];
     if (st->status != CM_DEV_OK || pass >= st->n_passes) return;
     const uint32_t n = st->n_valid;
+    if (blockIdx.x * CM_TILE >= n) return;             // tiles past the data are never read
     const uint32_t shift = pass * CM_RADIX_BITS;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t first = blockIdx.x * CM_TILE + w * (64 * CM_ITEMS) + lane;
     lh[threadIdx.x] = 0;
-    __syncthreads();
-    if (blockIdx.x * CM_TILE < n) {
+    uint32_t k[CM_ITEMS];
 #pragma unroll
-        for (int r = 0; r < CM_ITEMS; ++r) {
-            const uint32_t i = first + r * 64;
-            if (i < n) atomicAdd(&lh[(keys[i] >> shift) & (CM_RADIX - 1)], 1u);
-        }
+    for (int r = 0; r < CM_ITEMS; ++r) {
+        const uint32_t i = first + r * 64;
+        k[r] = (i < n) ? keys[i] : 0u;
     }
     __syncthreads();
-    hist[static_cast<size_t>(threadIdx.x) * n_tiles + blockIdx.x] = lh[threadIdx.x];
+#pragma unroll
+    for (int r = 0; r < CM_ITEMS; ++r)
+        if (first + r * 64 < n) atomicAdd(&lh[(k[r] >> shift) & (CM_RADIX - 1)], 1u);
+    __syncthreads();
+    const uint32_t c = lh[threadIdx.x];
+    hist[static_cast<size_t>(blockIdx.x) * CM_RADIX + threadIdx.x] = c;
+    if (c) atomicAdd(&grp[static_cast<size_t>(blockIdx.x / CM_GROUP) * CM_RADIX + threadIdx.x], c);
 }
 
-// One workgroup per digit: exclusive scan of that digit's counts over the tiles + digit total.
-__global__ __launch_bounds__(CM_BLOCK) void k_colscan(const CmFrameState* __restrict__ st,
-                                                      uint32_t* __restrict__ hist,
-                                                      uint32_t* __restrict__ totals,
-                                                      uint32_t pass, uint32_t n_tiles) {
-    __shared__ uint32_t lds[CM_WAVES];
+// Large frames only (more than CM_DIRECT_GROUPS groups): group totals -> exclusive prefix over
+// the groups, in place, plus the digit totals. One workgroup, thread d owns digit d.
+__global__ __launch_bounds__(CM_BLOCK) void k_gscan(const CmFrameState* __restrict__ st,
+                                                    uint32_t* __restrict__ grp,
+                                                    uint32_t* __restrict__ totals,
+                                                    uint32_t pass, uint32_t n_groups) {
     if (st->status != CM_DEV_OK || pass >= st->n_passes) return;
-    uint32_t* row = hist + static_cast<size_t>(blockIdx.x) * n_tiles;
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < n_tiles; base += CM_BLOCK) {
-        const uint32_t t = base + threadIdx.x;
-        const uint32_t v = (t < n_tiles) ? row[t] : 0u;
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan_u32(v, lds, &tot);
-        if (t < n_tiles) row[t] = carry + ex;
-        carry += tot;
+    uint32_t run = 0;
+    for (uint32_t g = 0; g < n_groups; g += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (g + q < n_groups) ? grp[static_cast<size_t>(g + q) * CM_RADIX + threadIdx.x] : 0u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (g + q < n_groups) grp[static_cast<size_t>(g + q) * CM_RADIX + threadIdx.x] = run;
+            run += v[q];
+        }
     }
-    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+    totals[threadIdx.x] = run;
 }
 
 // Lanes of the wave that hold the same 8-bit digit (among valid lanes).
@@ -364,8 +468,9 @@ __global__ __launch_bounds__(CM_BLOCK) void k_scatter(CmFrameState* __restrict__
                                                       uint32_t* __restrict__ keys_out,
                                                       uint32_t* __restrict__ vals_out,
                                                       const uint32_t* __restrict__ hist,
+                                                      const uint32_t* __restrict__ grp,
                                                       const uint32_t* __restrict__ totals,
-                                                      uint32_t pass, uint32_t n_tiles, uint32_t n_padded) {
+                                                      uint32_t pass, uint32_t n_groups, uint32_t n_padded) {
     __shared__ uint32_t whist[CM_WAVES][CM_RADIX];
     __shared__ uint32_t gofs[CM_RADIX];
     __shared__ uint32_t skey[CM_TILE];
@@ -373,17 +478,41 @@ __global__ __launch_bounds__(CM_BLOCK) void k_scatter(CmFrameState* __restrict__
     __shared__ uint32_t lds[CM_WAVES];
     __shared__ uint32_t s_tile_valid;
     if (st->status != CM_DEV_OK || pass >= st->n_passes) return;
-    const uint32_t n = FIRST ? n_padded : st->n_valid;
     const uint32_t tile = blockIdx.x;
     const uint32_t shift = pass * CM_RADIX_BITS;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t first = tile * CM_TILE + w * (64 * CM_ITEMS) + lane;
 
-    // Global base of every digit: exclusive scan of the digit totals.
+    // Items of digit d written before this tile's (thread d): every smaller digit of the whole
+    // frame (gbase) + digit d in earlier groups + digit d in earlier tiles of this group.
+    const uint32_t grp_id = tile / CM_GROUP;
+    uint32_t before = 0, my_total = 0;
+    if (totals) {                                       // large frame: k_gscan left prefixes
+        my_total = totals[threadIdx.x];
+        before = grp[static_cast<size_t>(grp_id) * CM_RADIX + threadIdx.x];
+    } else {
+        for (uint32_t g = 0; g < n_groups; g += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (g + q < n_groups) ? grp[static_cast<size_t>(g + q) * CM_RADIX + threadIdx.x] : 0u;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { my_total += v[q]; before += (g + q < grp_id) ? v[q] : 0u; }
+        }
+    }
+    {
+        const uint32_t t0 = grp_id * CM_GROUP;
+        for (uint32_t t = t0; t < tile; t += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (t + q < tile) ? hist[static_cast<size_t>(t + q) * CM_RADIX + threadIdx.x] : 0u;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) before += v[q];
+        }
+    }
     uint32_t gtot;
-    const uint32_t my_total = totals[threadIdx.x];
     const uint32_t gbase = block_excl_scan_u32(my_total, lds, &gtot);
     if (FIRST && tile == 0 && threadIdx.x == 0) st->n_valid = gtot;
+    const uint32_t n = FIRST ? n_padded : gtot;        // every pass sorts the same valid items
     if (tile * CM_TILE >= n) return;                   // uniform: empty tile (after the scan's barriers)
 
 #pragma unroll
@@ -425,7 +554,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_scatter(CmFrameState* __restrict__
         whist[1][d] = dbase + c0;
         whist[2][d] = dbase + c0 + c1;
         whist[3][d] = dbase + c0 + c1 + c2;
-        gofs[d] = gbase + hist[static_cast<size_t>(d) * n_tiles + tile] - dbase;
+        gofs[d] = gbase + before - dbase;
         if (d == 0) s_tile_valid = tile_valid;
     }
     __syncthreads();
@@ -456,77 +585,13 @@ __global__ __launch_bounds__(CM_BLOCK) void k_scatter(CmFrameState* __restrict__
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// K3a: kept voxels per tile of the sorted keys. A run is owned by the tile holding its head; it is
-// kept iff it reaches min_points_per_voxel (A.4 step 7), i.e. keys[head + min_pts - 1] == key.
-// ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ const uint32_t* pick(const CmFrameState* st, const uint32_t* a, const uint32_t* b) {
     return (st->n_passes & 1u) ? b : a;      // pass p reads A when p is even and writes the other
 }
 
-__global__ __launch_bounds__(CM_BLOCK) void k_seg_count(const CmFrameState* __restrict__ st,
-                                                        const uint32_t* __restrict__ keys_a,
-                                                        const uint32_t* __restrict__ keys_b,
-                                                        uint32_t* __restrict__ tile_counts,
-                                                        uint32_t min_pts) {
-    __shared__ uint32_t lds[CM_WAVES];
-    if (st->status != CM_DEV_OK) return;
-    const uint32_t n = st->n_valid;
-    const uint32_t* __restrict__ keys = pick(st, keys_a, keys_b);
-    const uint32_t base = blockIdx.x * CM_SEG_TILE;
-    uint32_t cnt = 0;
-    if (base < n) {
-#pragma unroll
-        for (int j = 0; j < CM_SEG_ITEMS; ++j) {
-            const uint32_t i = base + j * CM_BLOCK + threadIdx.x;
-            if (i < n) {
-                const uint32_t k = keys[i];
-                const bool head = (i == 0) || (keys[i - 1] != k);
-                bool keep = head;
-                if (head && min_pts > 1) {
-                    const uint32_t e = i + min_pts - 1;
-                    keep = (e >= i) && (e < n) && (keys[e] == k);
-                }
-                cnt += keep ? 1u : 0u;
-            }
-        }
-    }
-    const uint32_t tot = block_sum_u32(cnt, lds);
-    if (threadIdx.x == 0) tile_counts[blockIdx.x] = tot;
-}
-
 // ------------------------------------------------------------------------------------------------
-// K3s: exclusive scan of the tile counts, n_out and the frame's final status; prepares the state
-// buffer of the NEXT frame (zero) so no memset sits between frames.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(CM_BLOCK) void k_finalize(CmFrameState* __restrict__ st,
-                                                       CmFrameState* __restrict__ st_next,
-                                                       uint32_t* __restrict__ tile_counts,
-                                                       uint32_t n_seg_tiles_max) {
-    __shared__ uint32_t lds[CM_WAVES];
-    if (st_next && threadIdx.x < sizeof(CmFrameState) / 4)
-        reinterpret_cast<uint32_t*>(st_next)[threadIdx.x] = 0;
-    if (st->status != CM_DEV_OK) return;
-    const uint32_t n = st->n_valid;
-    if (n == 0) {
-        if (threadIdx.x == 0) { st->status = CM_DEV_EMPTY; st->n_out = 0; }
-        return;
-    }
-    const uint32_t n_tiles = (n + CM_SEG_TILE - 1) / CM_SEG_TILE;
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < n_tiles; base += CM_BLOCK) {
-        const uint32_t t = base + threadIdx.x;
-        const uint32_t v = (t < n_tiles && t < n_seg_tiles_max) ? tile_counts[t] : 0u;
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan_u32(v, lds, &tot);
-        if (t < n_tiles && t < n_seg_tiles_max) tile_counts[t] = carry + ex;
-        carry += tot;
-    }
-    if (threadIdx.x == 0) { st->n_out = carry; st->n_seg_tiles = n_tiles; }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K3b: gather the points of a sorted tile, segmented centroid reduction, threshold, compaction.
+// K3: kept voxels per sorted tile (published), gather, segmented centroid reduction, threshold,
+// compaction.
 // Thread t owns 8 consecutive sorted items; runs closed inside a thread are summed sequentially in
 // sorted (= stable point) order, runs crossing threads by a wave64 segmented suffix scan (DPP
 // shuffles), runs crossing waves through LDS, runs crossing the tile by a cooperative extension
@@ -565,13 +630,26 @@ __device__ __forceinline__ Pt gather_point(const SensorLds* __restrict__ tab, ui
     return o;
 }
 
+// Spin (bounded) until another workgroup of this launch has published its word. The word carries
+// its own flag (bit 31), so no ordering with other data is needed; relaxed agent-scope accesses go
+// past the non-coherent L1 (guide: data-is-the-flag granules).
+__device__ __forceinline__ uint32_t wait_published(uint32_t* p, uint32_t* err) {
+    for (uint32_t spins = 0;; ++spins) {
+        const uint32_t v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v & 0x80000000u) return v & 0x7FFFFFFFu;
+        if (spins > (1u << 20)) { *err = 1u; return 0u; }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
 __global__ __launch_bounds__(CM_BLOCK) void k_seg_reduce(const CmFrameDev* __restrict__ fd,
-                                                         const CmFrameState* __restrict__ st,
+                                                         CmFrameState* __restrict__ st,
+                                                         CmFrameState* __restrict__ st_next,
                                                          const uint32_t* __restrict__ keys_a,
                                                          const uint32_t* __restrict__ vals_a,
                                                          const uint32_t* __restrict__ keys_b,
                                                          const uint32_t* __restrict__ vals_b,
-                                                         const uint32_t* __restrict__ tile_offs,
+                                                         uint32_t* __restrict__ sync_words,
                                                          float4* __restrict__ out,
                                                          uint32_t* __restrict__ out_key,
                                                          uint32_t* __restrict__ out_cnt) {
@@ -582,17 +660,11 @@ __global__ __launch_bounds__(CM_BLOCK) void k_seg_reduce(const CmFrameDev* __res
     __shared__ float s_ext[CM_WAVES][4];
     __shared__ uint32_t s_extc[CM_WAVES];
     __shared__ uint32_t lds[CM_WAVES];
-    if (st->status != CM_DEV_OK) return;
-    const uint32_t n = st->n_valid;
-    const uint32_t base = blockIdx.x * CM_SEG_TILE;
-    if (base >= n) return;
-    const uint32_t* __restrict__ keys = pick(st, keys_a, keys_b);
-    const uint32_t* __restrict__ vals = pick(st, vals_a, vals_b);
+    __shared__ uint32_t s_tile;
+    // Tiles are handed out in arrival order, so every tile with a smaller id is already running
+    // (its published count is never waited for in vain, whatever the dispatch order).
+    if (threadIdx.x == 0) s_tile = atomicAdd(&sync_words[0], 1u);
     const uint32_t n_sensors = fd->n_sensors;
-    const uint32_t min_pts = fd->min_pts > 1 ? fd->min_pts : 1u;
-    const bool all_fields = fd->downsample_all != 0;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-
     if (threadIdx.x < n_sensors) {
         const CmSensorDev& g = fd->s[threadIdx.x];
         SensorLds& t = tab[threadIdx.x];
@@ -601,11 +673,28 @@ __global__ __launch_bounds__(CM_BLOCK) void k_seg_reduce(const CmFrameDev* __res
         for (int k = 0; k < 12; ++k) t.m[k] = g.m[k];
     }
     __syncthreads();
+    const uint32_t tile = s_tile;
+    if (tile == 0 && st_next && threadIdx.x < sizeof(CmFrameState) / 4)
+        reinterpret_cast<uint32_t*>(st_next)[threadIdx.x] = 0;          // next frame starts from zero
+    if (st->status != CM_DEV_OK) return;
+    const uint32_t n = st->n_valid;
+    if (n == 0) {
+        if (tile == 0 && threadIdx.x == 0) { st->status = CM_DEV_EMPTY; st->n_out = 0; }
+        return;
+    }
+    const uint32_t base = tile * CM_SEG_TILE;
+    if (base >= n) return;
+    const uint32_t n_tiles = (n + CM_SEG_TILE - 1) / CM_SEG_TILE;
+    const uint32_t* __restrict__ keys = pick(st, keys_a, keys_b);
+    const uint32_t* __restrict__ vals = pick(st, vals_a, vals_b);
+    const uint32_t min_pts = fd->min_pts > 1 ? fd->min_pts : 1u;
+    const bool all_fields = fd->downsample_all != 0;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 
     const uint32_t tile_n = min(static_cast<uint32_t>(CM_SEG_TILE), n - base);
     const uint32_t i0 = base + threadIdx.x * CM_SEG_ITEMS;
 
-    // keys + previous key
+    // keys of the chunk, the key before it and the key after it
     uint32_t k[CM_SEG_ITEMS];
     if (i0 + CM_SEG_ITEMS <= n) {
         const uint4 a = *reinterpret_cast<const uint4*>(keys + i0);
@@ -616,37 +705,57 @@ __global__ __launch_bounds__(CM_BLOCK) void k_seg_reduce(const CmFrameDev* __res
         for (int j = 0; j < CM_SEG_ITEMS; ++j) k[j] = (i0 + j < n) ? keys[i0 + j] : 0u;
     }
     const uint32_t kprev = (i0 > 0 && i0 < n) ? keys[i0 - 1] : 0u;
+    const bool has_next = i0 + CM_SEG_ITEMS < n;
+    const uint32_t knext = has_next ? keys[i0 + CM_SEG_ITEMS] : 0u;
 
-    // gather + transform
-    Pt p[CM_SEG_ITEMS];
-    if (i0 + CM_SEG_ITEMS <= n) {
-        const uint4 a = *reinterpret_cast<const uint4*>(vals + i0);
-        const uint4 b = *reinterpret_cast<const uint4*>(vals + i0 + 4);
-        const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-        for (int j = 0; j < CM_SEG_ITEMS; ++j) p[j] = gather_point(tab, n_sensors, v[j]);
-    } else {
-#pragma unroll
-        for (int j = 0; j < CM_SEG_ITEMS; ++j) {
-            if (i0 + j < n) p[j] = gather_point(tab, n_sensors, vals[i0 + j]);
-            else { p[j].x = p[j].y = p[j].z = p[j].i = 0.f; }
-        }
-    }
-    if (!all_fields) {
-#pragma unroll
-        for (int j = 0; j < CM_SEG_ITEMS; ++j) p[j].i = 0.f;
-    }
-
-    // head flags
-    uint32_t heads = 0;          // bit j: item j starts a run
-    uint32_t live = 0;           // bit j: item j exists
+    // head flags; a run is kept iff it reaches min_points_per_voxel (A.4 step 7), i.e.
+    // keys[head + min_pts - 1] == key. `need`: items of runs longer than one point.
+    uint32_t heads = 0, live = 0, need = 0, nkeep_look = 0;
 #pragma unroll
     for (int j = 0; j < CM_SEG_ITEMS; ++j) {
         const uint32_t i = i0 + j;
         if (i < n) {
             live |= 1u << j;
-            const uint32_t pk = (j == 0) ? kprev : k[j - 1];
-            if (i == 0 || pk != k[j]) heads |= 1u << j;
+            const uint32_t pk = (j == 0) ? kprev : k[(j + CM_SEG_ITEMS - 1) % CM_SEG_ITEMS];
+            const bool head = (i == 0) || (pk != k[j]);
+            const bool same_next = (j == CM_SEG_ITEMS - 1) ? (has_next && knext == k[j])
+                                                           : (i + 1 < n && k[(j + 1) % CM_SEG_ITEMS] == k[j]);
+            if (head) {
+                heads |= 1u << j;
+                bool keep = true;
+                if (min_pts == 2) keep = same_next;
+                else if (min_pts > 2) {
+                    const uint32_t e = i + min_pts - 1;
+                    keep = (e >= i) && (e < n) && (keys[e] == k[j]);
+                }
+                nkeep_look += keep ? 1u : 0u;
+            }
+            if (min_pts <= 1 || !head || same_next) need |= 1u << j;
+        }
+    }
+    // Publish this tile's kept-voxel count right away; the output offset is summed much later.
+    const uint32_t tile_keep = block_sum_u32(nkeep_look, lds);
+    if (threadIdx.x == 0)
+        __hip_atomic_store(&sync_words[CM_SYNC_HEADER + tile], tile_keep | 0x80000000u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+
+    // gather + transform (only points whose run can survive the threshold)
+    Pt p[CM_SEG_ITEMS];
+    {
+        uint32_t v[CM_SEG_ITEMS];
+        if (i0 + CM_SEG_ITEMS <= n) {
+            const uint4 a = *reinterpret_cast<const uint4*>(vals + i0);
+            const uint4 b = *reinterpret_cast<const uint4*>(vals + i0 + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < CM_SEG_ITEMS; ++j) v[j] = (i0 + j < n) ? vals[i0 + j] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < CM_SEG_ITEMS; ++j) {
+            if (need >> j & 1u) p[j] = gather_point(tab, n_sensors, v[j]);
+            else { p[j].x = p[j].y = p[j].z = p[j].i = 0.f; }
+            if (!all_fields) p[j].i = 0.f;
         }
     }
 
@@ -769,8 +878,15 @@ __global__ __launch_bounds__(CM_BLOCK) void k_seg_reduce(const CmFrameDev* __res
 #pragma unroll
     for (int j = 0; j < CM_SEG_ITEMS; ++j)
         if ((fmask >> j & 1u) && fin[j].c >= min_pts) ++nkeep;
+    // Output offset of this tile = kept voxels of every earlier tile (published long ago).
+    uint32_t before = 0, spin_err = 0;
+    for (uint32_t t = threadIdx.x; t < tile; t += CM_BLOCK)
+        before += wait_published(&sync_words[CM_SYNC_HEADER + t], &spin_err);
+    const uint32_t tile_off = block_sum_u32(before, lds);
+    if (spin_err) st->err = 1u;
+    if (tile == n_tiles - 1 && threadIdx.x == 0) st->n_out = tile_off + tile_keep;
     uint32_t tot;
-    uint32_t slot = tile_offs[blockIdx.x] + block_excl_scan_u32(nkeep, lds, &tot);
+    uint32_t slot = tile_off + block_excl_scan_u32(nkeep, lds, &tot);
 #pragma unroll
     for (int j = 0; j <= CM_SEG_ITEMS; ++j) {
         const bool is_last = (j == CM_SEG_ITEMS);
@@ -871,48 +987,41 @@ __global__ __launch_bounds__(CM_BLOCK) void k_merged_write(const CmFrameDev* __r
 void cmk_setup(hipStream_t s, const CmFrameDev& f, CmFrameDev* d_frame) {
     CM_LAUNCH(k_setup, 1, 64, s, f, d_frame);
 }
-void cmk_minmax(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t n_tiles) {
-    CM_LAUNCH(k_minmax, n_tiles, CM_BLOCK, s, fd, st);
+void cmk_minmax(hipStream_t s, const CmFrameDev* fd, float* partials, uint32_t n_blocks) {
+    CM_LAUNCH(k_minmax, n_blocks, CM_BLOCK, s, fd, partials);
 }
-void cmk_bounds(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, int from_crop) {
-    CM_LAUNCH(k_bounds, 1, 64, s, fd, st, from_crop);
+void cmk_keys(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* keys, uint32_t* hist,
+              uint32_t* grp_acc, uint32_t* grp_clear_a, uint32_t* grp_clear_b, uint32_t n_group_words,
+              uint32_t n_clear_a_words, uint32_t* sync_words, const float* partials, uint32_t n_partials,
+              int from_crop, uint32_t n_tiles) {
+    CM_LAUNCH(k_keys, n_tiles, CM_BLOCK, s, fd, st, keys, hist, grp_acc, grp_clear_a, grp_clear_b,
+              n_group_words, n_clear_a_words, sync_words, partials, n_partials, from_crop);
 }
-void cmk_keys(hipStream_t s, const CmFrameDev* fd, const CmFrameState* st, uint32_t* keys, uint32_t* hist,
-              uint32_t n_tiles) {
-    CM_LAUNCH(k_keys, n_tiles, CM_BLOCK, s, fd, st, keys, hist);
+void cmk_hist(hipStream_t s, const CmFrameState* st, const uint32_t* keys, uint32_t* hist, uint32_t* grp,
+              uint32_t pass, uint32_t n_tiles) {
+    CM_LAUNCH(k_hist, n_tiles, CM_BLOCK, s, st, keys, hist, grp, pass);
 }
-void cmk_hist(hipStream_t s, const CmFrameState* st, const uint32_t* keys, uint32_t* hist, uint32_t pass,
-              uint32_t n_tiles) {
-    CM_LAUNCH(k_hist, n_tiles, CM_BLOCK, s, st, keys, hist, pass, n_tiles);
-}
-void cmk_colscan(hipStream_t s, const CmFrameState* st, uint32_t* hist, uint32_t* totals, uint32_t pass,
-                 uint32_t n_tiles) {
-    CM_LAUNCH(k_colscan, CM_RADIX, CM_BLOCK, s, st, hist, totals, pass, n_tiles);
+void cmk_gscan(hipStream_t s, const CmFrameState* st, uint32_t* grp, uint32_t* totals, uint32_t pass,
+               uint32_t n_groups) {
+    CM_LAUNCH(k_gscan, 1, CM_BLOCK, s, st, grp, totals, pass, n_groups);
 }
 void cmk_scatter(hipStream_t s, CmFrameState* st, const uint32_t* keys_in, const uint32_t* vals_in,
-                 uint32_t* keys_out, uint32_t* vals_out, const uint32_t* hist, const uint32_t* totals,
-                 uint32_t pass, uint32_t n_tiles, uint32_t n_padded) {
+                 uint32_t* keys_out, uint32_t* vals_out, const uint32_t* hist, const uint32_t* grp,
+                 const uint32_t* totals, uint32_t pass, uint32_t n_tiles, uint32_t n_groups,
+                 uint32_t n_padded) {
     if (pass == 0)
-        CM_LAUNCH(k_scatter<true>, n_tiles, CM_BLOCK, s, st, keys_in, vals_in, keys_out, vals_out, hist,
-                  totals, pass, n_tiles, n_padded);
+        CM_LAUNCH(k_scatter<true>, n_tiles, CM_BLOCK, s, st, keys_in, vals_in, keys_out, vals_out, hist, grp,
+                  totals, pass, n_groups, n_padded);
     else
-        CM_LAUNCH(k_scatter<false>, n_tiles, CM_BLOCK, s, st, keys_in, vals_in, keys_out, vals_out, hist,
-                  totals, pass, n_tiles, n_padded);
+        CM_LAUNCH(k_scatter<false>, n_tiles, CM_BLOCK, s, st, keys_in, vals_in, keys_out, vals_out, hist, grp,
+                  totals, pass, n_groups, n_padded);
 }
-void cmk_seg_count(hipStream_t s, const CmFrameState* st, const uint32_t* keys_a, const uint32_t* keys_b,
-                   uint32_t* tile_counts, uint32_t min_pts, uint32_t n_seg_tiles) {
-    CM_LAUNCH(k_seg_count, n_seg_tiles, CM_BLOCK, s, st, keys_a, keys_b, tile_counts, min_pts);
-}
-void cmk_finalize(hipStream_t s, CmFrameState* st, CmFrameState* st_next, uint32_t* tile_counts,
-                  uint32_t n_seg_tiles) {
-    CM_LAUNCH(k_finalize, 1, CM_BLOCK, s, st, st_next, tile_counts, n_seg_tiles);
-}
-void cmk_seg_reduce(hipStream_t s, const CmFrameDev* fd, const CmFrameState* st, const uint32_t* keys_a,
-                    const uint32_t* vals_a, const uint32_t* keys_b, const uint32_t* vals_b,
-                    const uint32_t* tile_offs, void* out, uint32_t* out_key, uint32_t* out_cnt,
-                    uint32_t n_seg_tiles) {
-    CM_LAUNCH(k_seg_reduce, n_seg_tiles, CM_BLOCK, s, fd, st, keys_a, vals_a, keys_b, vals_b, tile_offs,
-              reinterpret_cast<float4*>(out), out_key, out_cnt);
+void cmk_seg_reduce(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next,
+                    const uint32_t* keys_a, const uint32_t* vals_a, const uint32_t* keys_b,
+                    const uint32_t* vals_b, uint32_t* sync_words, void* out, uint32_t* out_key,
+                    uint32_t* out_cnt, uint32_t n_seg_tiles) {
+    CM_LAUNCH(k_seg_reduce, n_seg_tiles, CM_BLOCK, s, fd, st, st_next, keys_a, vals_a, keys_b, vals_b,
+              sync_words, reinterpret_cast<float4*>(out), out_key, out_cnt);
 }
 void cmk_merged(hipStream_t s, const CmFrameDev* fd, uint32_t* tile_counts, uint32_t* total, void* out,
                 uint32_t n_tiles) {
