@@ -462,7 +462,7 @@ __device__ __forceinline__ unsigned long long match_digit(uint32_t digit, bool v
 // Stable scatter of one tile by one digit. FIRST: values are the padded global indices and
 // CM_INVALID_KEY slots are dropped (this is where the concatenated cloud gets compacted).
 template <bool FIRST>
-__global__ __launch_bounds__(CM_BLOCK) void k_scatter(CmFrameState* __restrict__ st,
+__global__ __launch_bounds__(CM_BLOCK, 4) void k_scatter(CmFrameState* __restrict__ st,
                                                       const uint32_t* __restrict__ keys_in,
                                                       const uint32_t* __restrict__ vals_in,
                                                       uint32_t* __restrict__ keys_out,
@@ -483,6 +483,18 @@ __global__ __launch_bounds__(CM_BLOCK) void k_scatter(CmFrameState* __restrict__
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t first = tile * CM_TILE + w * (64 * CM_ITEMS) + lane;
 
+    // All loads of the tile go out first (keys, and the values they carry); the cross-tile sums
+    // below run while they are in flight. Slots past n are never counted (n is known only after
+    // the sums, so bound the loads by the launch-time upper bound).
+    const uint32_t n_max = n_padded;
+    uint32_t key[CM_ITEMS], val[CM_ITEMS];
+#pragma unroll
+    for (int r = 0; r < CM_ITEMS; ++r) {
+        const uint32_t i = first + r * 64;
+        key[r] = (i < n_max) ? keys_in[i] : CM_INVALID_KEY;
+        val[r] = FIRST ? i : ((i < n_max) ? vals_in[i] : 0u);
+    }
+
     // Items of digit d written before this tile's (thread d): every smaller digit of the whole
     // frame (gbase) + digit d in earlier groups + digit d in earlier tiles of this group.
     const uint32_t grp_id = tile / CM_GROUP;
@@ -491,22 +503,22 @@ __global__ __launch_bounds__(CM_BLOCK) void k_scatter(CmFrameState* __restrict__
         my_total = totals[threadIdx.x];
         before = grp[static_cast<size_t>(grp_id) * CM_RADIX + threadIdx.x];
     } else {
-        for (uint32_t g = 0; g < n_groups; g += 8) {
-            uint32_t v[8];
+        for (uint32_t g = 0; g < n_groups; g += 16) {
+            uint32_t v[16];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = (g + q < n_groups) ? grp[static_cast<size_t>(g + q) * CM_RADIX + threadIdx.x] : 0u;
+            for (int q = 0; q < 16; ++q) v[q] = (g + q < n_groups) ? grp[static_cast<size_t>(g + q) * CM_RADIX + threadIdx.x] : 0u;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { my_total += v[q]; before += (g + q < grp_id) ? v[q] : 0u; }
+            for (int q = 0; q < 16; ++q) { my_total += v[q]; before += (g + q < grp_id) ? v[q] : 0u; }
         }
     }
     {
         const uint32_t t0 = grp_id * CM_GROUP;
-        for (uint32_t t = t0; t < tile; t += 8) {
-            uint32_t v[8];
+        for (uint32_t t = t0; t < tile; t += 16) {
+            uint32_t v[16];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = (t + q < tile) ? hist[static_cast<size_t>(t + q) * CM_RADIX + threadIdx.x] : 0u;
+            for (int q = 0; q < 16; ++q) v[q] = (t + q < tile) ? hist[static_cast<size_t>(t + q) * CM_RADIX + threadIdx.x] : 0u;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) before += v[q];
+            for (int q = 0; q < 16; ++q) before += v[q];
         }
     }
     uint32_t gtot;
@@ -517,13 +529,6 @@ __global__ __launch_bounds__(CM_BLOCK) void k_scatter(CmFrameState* __restrict__
 
 #pragma unroll
     for (int q = 0; q < CM_WAVES; ++q) whist[q][threadIdx.x] = 0;
-
-    uint32_t key[CM_ITEMS];
-#pragma unroll
-    for (int r = 0; r < CM_ITEMS; ++r) {
-        const uint32_t i = first + r * 64;
-        key[r] = (i < n) ? keys_in[i] : CM_INVALID_KEY;
-    }
     __syncthreads();
 
     // Rank inside the wave, rounds in order, lanes in order: stable.
@@ -567,7 +572,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_scatter(CmFrameState* __restrict__
             const uint32_t digit = (key[r] >> shift) & (CM_RADIX - 1);
             const uint32_t pos = whist[w][digit] + rank[r];
             skey[pos] = key[r];
-            sval[pos] = FIRST ? i : vals_in[i];
+            sval[pos] = val[r];
         }
     }
     __syncthreads();
@@ -694,19 +699,32 @@ __global__ __launch_bounds__(CM_BLOCK) void k_seg_reduce(const CmFrameDev* __res
     const uint32_t tile_n = min(static_cast<uint32_t>(CM_SEG_TILE), n - base);
     const uint32_t i0 = base + threadIdx.x * CM_SEG_ITEMS;
 
-    // keys of the chunk, the key before it and the key after it
-    uint32_t k[CM_SEG_ITEMS];
+    // Every load that does not depend on another goes out now: the keys of the chunk, the key
+    // before and after it, the point indices the keys carry, and the first keys past the tile
+    // (for the extension of its last run).
+    uint32_t k[CM_SEG_ITEMS], v[CM_SEG_ITEMS];
     if (i0 + CM_SEG_ITEMS <= n) {
         const uint4 a = *reinterpret_cast<const uint4*>(keys + i0);
         const uint4 b = *reinterpret_cast<const uint4*>(keys + i0 + 4);
+        const uint4 c = *reinterpret_cast<const uint4*>(vals + i0);
+        const uint4 d = *reinterpret_cast<const uint4*>(vals + i0 + 4);
         k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w;
+        v[0] = c.x; v[1] = c.y; v[2] = c.z; v[3] = c.w; v[4] = d.x; v[5] = d.y; v[6] = d.z; v[7] = d.w;
     } else {
 #pragma unroll
-        for (int j = 0; j < CM_SEG_ITEMS; ++j) k[j] = (i0 + j < n) ? keys[i0 + j] : 0u;
+        for (int j = 0; j < CM_SEG_ITEMS; ++j) {
+            k[j] = (i0 + j < n) ? keys[i0 + j] : 0u;
+            v[j] = (i0 + j < n) ? vals[i0 + j] : 0u;
+        }
     }
     const uint32_t kprev = (i0 > 0 && i0 < n) ? keys[i0 - 1] : 0u;
     const bool has_next = i0 + CM_SEG_ITEMS < n;
     const uint32_t knext = has_next ? keys[i0 + CM_SEG_ITEMS] : 0u;
+    const uint32_t tile_end = base + tile_n;
+    const uint32_t klast = keys[tile_end - 1];
+    const uint32_t jext0 = tile_end + threadIdx.x;
+    const uint32_t kext0 = (jext0 < n) ? keys[jext0] : 0u;
+    const uint32_t vext0 = (jext0 < n) ? vals[jext0] : 0u;
 
     // head flags; a run is kept iff it reaches min_points_per_voxel (A.4 step 7), i.e.
     // keys[head + min_pts - 1] == key. `need`: items of runs longer than one point.
@@ -741,35 +759,23 @@ __global__ __launch_bounds__(CM_BLOCK) void k_seg_reduce(const CmFrameDev* __res
 
     // gather + transform (only points whose run can survive the threshold)
     Pt p[CM_SEG_ITEMS];
-    {
-        uint32_t v[CM_SEG_ITEMS];
-        if (i0 + CM_SEG_ITEMS <= n) {
-            const uint4 a = *reinterpret_cast<const uint4*>(vals + i0);
-            const uint4 b = *reinterpret_cast<const uint4*>(vals + i0 + 4);
-            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-        } else {
 #pragma unroll
-            for (int j = 0; j < CM_SEG_ITEMS; ++j) v[j] = (i0 + j < n) ? vals[i0 + j] : 0u;
-        }
-#pragma unroll
-        for (int j = 0; j < CM_SEG_ITEMS; ++j) {
-            if (need >> j & 1u) p[j] = gather_point(tab, n_sensors, v[j]);
-            else { p[j].x = p[j].y = p[j].z = p[j].i = 0.f; }
-            if (!all_fields) p[j].i = 0.f;
-        }
+    for (int j = 0; j < CM_SEG_ITEMS; ++j) {
+        if (need >> j & 1u) p[j] = gather_point(tab, n_sensors, v[j]);
+        else { p[j].x = p[j].y = p[j].z = p[j].i = 0.f; }
+        if (!all_fields) p[j].i = 0.f;
     }
 
     // Extension: items after the tile that continue its last run (owned by this workgroup).
     Acc ext = {0.f, 0.f, 0.f, 0.f, 0u};
     {
-        const uint32_t end = base + tile_n;
-        const uint32_t klast = keys[end - 1];
         bool any = false;
         for (uint32_t off = 0;; off += CM_BLOCK) {
-            const uint32_t j = end + off + threadIdx.x;
-            const bool ok = (j < n) && (keys[j] == klast);
+            const uint32_t j = tile_end + off + threadIdx.x;
+            const uint32_t kj = (off == 0) ? kext0 : ((j < n) ? keys[j] : 0u);
+            const bool ok = (j < n) && (kj == klast);
             if (ok) {
-                Pt q = gather_point(tab, n_sensors, vals[j]);
+                Pt q = gather_point(tab, n_sensors, (off == 0) ? vext0 : vals[j]);
                 if (!all_fields) q.i = 0.f;
                 ext.x = __fadd_rn(ext.x, q.x); ext.y = __fadd_rn(ext.y, q.y);
                 ext.z = __fadd_rn(ext.z, q.z); ext.i = __fadd_rn(ext.i, q.i);
