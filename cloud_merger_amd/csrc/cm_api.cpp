@@ -8,7 +8,7 @@
 //   keys_a/b, vals_a/b  4 x N x u32   radix ping-pong: voxel index, padded point index
 //   hist              (N/4096) x 256 u32   digit counts per tile (one coalesced row each)
 //   grp               5 x (N/4096/32) x 256 u32   digit counts per group of 32 tiles, per pass
-//   sync_words        64 + N/2048 u32 tile ticket + published kept-voxel count per sorted tile
+//   seg_tile_counts   N/2048 u32      kept voxels per sorted tile (+ totals per 256 tiles)
 //   out               N x 16 B        centroids x,y,z,intensity (ascending voxel index = PCL order)
 //   out_key/out_cnt   N x u32 each    only with CM_FLAG_OCCUPANCY
 #include <hip/hip_runtime.h>
@@ -50,7 +50,7 @@ struct cm_ctx {
 
     uint32_t cap_padded = 0, cap_tiles = 0, cap_seg_tiles = 0;
     uint32_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr;
-    uint32_t *hist = nullptr, *grp = nullptr, *totals = nullptr, *seg_counts = nullptr, *sync_words = nullptr;
+    uint32_t *hist = nullptr, *grp = nullptr, *totals = nullptr, *seg_counts = nullptr, *seg_tile_counts = nullptr, *seg_groups = nullptr;
     uint32_t cap_groups = 0, frame_seq = 0;
     float* partials = nullptr;
     uint32_t *out_key = nullptr, *out_cnt = nullptr, *merged_total = nullptr;
@@ -167,7 +167,7 @@ void prof_mark(cm_ctx* c, const char* name) {
 void free_all(cm_ctx* c) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(c->keys_a); F(c->keys_b); F(c->vals_a); F(c->vals_b); F(c->hist); F(c->totals);
-    F(c->seg_counts); F(c->sync_words); F(c->grp); F(c->partials); F(c->out_key); F(c->out_cnt); F(c->merged_total); F(c->out); F(c->merged);
+    F(c->seg_counts); F(c->seg_tile_counts); F(c->seg_groups); F(c->grp); F(c->partials); F(c->out_key); F(c->out_cnt); F(c->merged_total); F(c->out); F(c->merged);
     F(c->d_frame); F(c->d_state[0]); F(c->d_state[1]);
     if (c->h_state) (void)hipHostFree(c->h_state);
     for (auto& s : c->slots) {
@@ -310,7 +310,8 @@ int enqueue(cm_ctx* c, const cm_params* p) {
     if (!c->from_crop) { prof_mark(c, "k_minmax"); cmk_minmax(st, c->d_frame, c->partials, n_partials); }
     prof_mark(c, "k_keys");
     cmk_keys(st, c->d_frame, state, c->keys_a, c->hist, grp0, grp0_next, c->grp + 2 * gstride, gw,
-             static_cast<uint32_t>(gstride), c->sync_words, c->partials, n_partials, c->from_crop ? 1 : 0, nt);
+             static_cast<uint32_t>(gstride), c->seg_groups, (nseg + CM_SEG_GROUP - 1) / CM_SEG_GROUP + 1,
+             c->partials, n_partials, c->from_crop ? 1 : 0, nt);
     // NOTE: k_keys clears 3*gw words starting at grp[2]; passes 1..3 therefore live at stride gw.
     for (uint32_t pass = 0; pass < passes; ++pass) {
         const bool even = (pass & 1u) == 0;
@@ -325,9 +326,12 @@ int enqueue(cm_ctx* c, const cm_params* p) {
         cmk_scatter(st, state, kin, vin, kout, vout, c->hist, grp, big ? c->totals : nullptr, pass, nt,
                     n_groups, f.n_padded);
     }
+    prof_mark(c, "k_seg_count");
+    uint32_t* seg_groups = nseg > CM_SEG_DIRECT_TILES ? c->seg_groups : nullptr;
+    cmk_seg_count(st, state, c->keys_a, c->keys_b, c->seg_tile_counts, seg_groups, f.min_pts, nseg);
     prof_mark(c, "k_seg_reduce");
     cmk_seg_reduce(st, c->d_frame, state, state_next, c->keys_a, c->vals_a, c->keys_b, c->vals_b,
-                   c->sync_words, c->out, c->out_key, c->out_cnt, nseg);
+                   c->seg_tile_counts, seg_groups, c->out, c->out_key, c->out_cnt, nseg);
     prof_mark(c, "end");
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->h_state, state, sizeof(CmFrameState), hipMemcpyDeviceToHost, st));
@@ -444,7 +448,8 @@ int cm_create(cm_ctx** out, int device, const cm_limits* lim) {
         ok = ok && A(reinterpret_cast<void**>(&c->grp), gbytes);
         ok = ok && hipMemset(c->grp, 0, gbytes) == hipSuccess;
     }
-    ok = ok && A(reinterpret_cast<void**>(&c->sync_words), static_cast<size_t>(CM_SYNC_HEADER + c->cap_seg_tiles) * 4);
+    ok = ok && A(reinterpret_cast<void**>(&c->seg_tile_counts), static_cast<size_t>(c->cap_seg_tiles + 1) * 4);
+    ok = ok && A(reinterpret_cast<void**>(&c->seg_groups), static_cast<size_t>(c->cap_seg_tiles / CM_SEG_GROUP + 2) * 32 * 4);
     ok = ok && A(reinterpret_cast<void**>(&c->partials), CM_MINMAX_BLOCKS * 8 * sizeof(float));
     ok = ok && A(reinterpret_cast<void**>(&c->totals), CM_RADIX * 4);
     ok = ok && A(reinterpret_cast<void**>(&c->seg_counts), static_cast<size_t>(c->cap_seg_tiles + c->cap_tiles) * 4);

@@ -22,8 +22,8 @@
 #define CM_SEG_TILE 2048      // sorted items per workgroup in the centroid kernel
 #define CM_SEG_ITEMS 8
 #define CM_MINMAX_BLOCKS 512  // workgroups (= partial records) of the min/max pass
-#define CM_SYNC_HEADER 64     // sync_words: [0] centroid tile ticket,
-                              // [CM_SYNC_HEADER + t] published kept-voxel count of sorted tile t
+#define CM_SEG_GROUP 256      // sorted tiles per kept-voxel group total (== CM_BLOCK)
+#define CM_SEG_DIRECT_TILES 4096  // up to this many sorted tiles the per-tile counts are summed directly
 
 // Point layouts the loaders special-case.
 #define CM_LAYOUT_XYZI16 0    // x,y,z,intensity @0,4,8,12, step 16, 16-B aligned: one dwordx4 load

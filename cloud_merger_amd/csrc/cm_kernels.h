@@ -9,8 +9,8 @@ void cmk_setup(hipStream_t s, const CmFrameDev& f, CmFrameDev* d_frame);
 void cmk_minmax(hipStream_t s, const CmFrameDev* fd, float* partials, uint32_t n_blocks);
 void cmk_keys(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* keys, uint32_t* hist,
               uint32_t* grp_acc, uint32_t* grp_clear_a, uint32_t* grp_clear_b, uint32_t n_group_words,
-              uint32_t n_clear_a_words, uint32_t* sync_words, const float* partials, uint32_t n_partials,
-              int from_crop, uint32_t n_tiles);
+              uint32_t n_clear_a_words, uint32_t* seg_groups, uint32_t n_seg_groups, const float* partials,
+              uint32_t n_partials, int from_crop, uint32_t n_tiles);
 void cmk_hist(hipStream_t s, const CmFrameState* st, const uint32_t* keys, uint32_t* hist, uint32_t* grp,
               uint32_t pass, uint32_t n_tiles);
 void cmk_gscan(hipStream_t s, const CmFrameState* st, uint32_t* grp, uint32_t* totals, uint32_t pass,
@@ -19,9 +19,11 @@ void cmk_scatter(hipStream_t s, CmFrameState* st, const uint32_t* keys_in, const
                  uint32_t* keys_out, uint32_t* vals_out, const uint32_t* hist, const uint32_t* grp,
                  const uint32_t* totals, uint32_t pass, uint32_t n_tiles, uint32_t n_groups,
                  uint32_t n_padded);
+void cmk_seg_count(hipStream_t s, const CmFrameState* st, const uint32_t* keys_a, const uint32_t* keys_b,
+                   uint32_t* counts, uint32_t* group_counts, uint32_t min_pts, uint32_t n_seg_tiles);
 void cmk_seg_reduce(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next,
                     const uint32_t* keys_a, const uint32_t* vals_a, const uint32_t* keys_b,
-                    const uint32_t* vals_b, uint32_t* sync_words, void* out, uint32_t* out_key,
-                    uint32_t* out_cnt, uint32_t n_seg_tiles);
+                    const uint32_t* vals_b, const uint32_t* counts, const uint32_t* group_counts, void* out,
+                    uint32_t* out_key, uint32_t* out_cnt, uint32_t n_seg_tiles);
 void cmk_merged(hipStream_t s, const CmFrameDev* fd, uint32_t* tile_counts, uint32_t* total, void* out,
                 uint32_t n_tiles);

@@ -8,8 +8,9 @@
 //   per 8-bit digit: k_hist (digits 1..3: counts per tile and per group), k_scatter (cross-tile
 //                    offsets summed in its prologue, stable LDS-tiled scatter); frames of more
 //                    than CM_DIRECT_GROUPS groups run k_gscan in between      [LDS-tiled LSD radix]
-//   k_seg_reduce K3  kept voxels per sorted tile (published), gather + wavefront segmented
-//                    centroid reduction, threshold, compaction                [16 B/voxel write]
+//   k_seg_count  K3a kept voxels per sorted tile and per group of tiles
+//   k_seg_reduce K3b gather + wavefront segmented centroid reduction, threshold, compaction
+//                                                                             [16 B/voxel write]
 //
 // Arithmetic restates what the reference gets from pcl_ros::transformPointCloud
 // (pc_preprocessing_main.cpp:322), pcl::PassThrough in getROI (:20-40) and pcl::VoxelGrid (:171-176);
@@ -311,8 +312,8 @@ __device__ __forceinline__ void compute_grid(const CmFrameDev* __restrict__ fd,
 // ------------------------------------------------------------------------------------------------
 // K1: grid set-up + transform + crop + linear voxel index (A.4 step 5) + digit-0 counts of the
 // tile (one coalesced row) and of its group of CM_GROUP tiles. Keys of cropped / non-finite /
-// padding slots are CM_INVALID_KEY and never enter the sort. Also clears the ticket word, the
-// words the centroid kernel's workgroups publish through and the group totals of every pass.
+// padding slots are CM_INVALID_KEY and never enter the sort. Also clears the group totals the
+// later kernels of the frame accumulate into.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(CM_BLOCK) void k_keys(const CmFrameDev* __restrict__ fd,
                                                    CmFrameState* __restrict__ st,
@@ -322,14 +323,14 @@ __global__ __launch_bounds__(CM_BLOCK) void k_keys(const CmFrameDev* __restrict_
                                                    uint32_t* __restrict__ grp_clear_a,
                                                    uint32_t* __restrict__ grp_clear_b,
                                                    uint32_t n_group_words, uint32_t n_clear_a_words,
-                                                   uint32_t* __restrict__ sync_words,
+                                                   uint32_t* __restrict__ seg_groups, uint32_t n_seg_groups,
                                                    const float* __restrict__ partials,
                                                    uint32_t n_partials, int from_crop) {
     __shared__ uint32_t lh[CM_RADIX];
     __shared__ float s_red[CM_WAVES][8];
     const uint32_t tile = blockIdx.x;
-    if (threadIdx.x < CM_TILE / CM_SEG_TILE) sync_words[CM_SYNC_HEADER + tile * (CM_TILE / CM_SEG_TILE) + threadIdx.x] = 0;
-    if (tile == 0 && threadIdx.x < CM_SYNC_HEADER) sync_words[threadIdx.x] = 0;
+    // kept-voxel totals per group of sorted tiles (k_seg_count accumulates into them)
+    for (uint32_t k = tile * CM_BLOCK + threadIdx.x; k < n_seg_groups * 32; k += gridDim.x * CM_BLOCK) seg_groups[k] = 0;
     // Clear the group totals of passes 1..3 (grp_clear_b, three arrays) and the pass-0 array the
     // NEXT frame accumulates into (grp_clear_a); this frame's pass-0 array (grp_acc) was cleared
     // by the previous frame.
@@ -595,6 +596,46 @@ __device__ __forceinline__ const uint32_t* pick(const CmFrameState* st, const ui
 }
 
 // ------------------------------------------------------------------------------------------------
+// K3a: kept voxels per tile of the sorted keys (+ totals per group of CM_SEG_GROUP tiles). A run is
+// owned by the tile holding its head; it is kept iff it reaches min_points_per_voxel (A.4 step 7),
+// i.e. keys[head + min_pts - 1] == key.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(CM_BLOCK) void k_seg_count(const CmFrameState* __restrict__ st,
+                                                        const uint32_t* __restrict__ keys_a,
+                                                        const uint32_t* __restrict__ keys_b,
+                                                        uint32_t* __restrict__ counts,
+                                                        uint32_t* __restrict__ group_counts,
+                                                        uint32_t min_pts) {
+    __shared__ uint32_t lds[CM_WAVES];
+    if (st->status != CM_DEV_OK) return;
+    const uint32_t n = st->n_valid;
+    const uint32_t base = blockIdx.x * CM_SEG_TILE;
+    if (base >= n) return;
+    const uint32_t* __restrict__ keys = pick(st, keys_a, keys_b);
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int j = 0; j < CM_SEG_ITEMS; ++j) {
+        const uint32_t i = base + j * CM_BLOCK + threadIdx.x;
+        if (i < n) {
+            const uint32_t k = keys[i];
+            const bool head = (i == 0) || (keys[i - 1] != k);
+            bool keep = head;
+            if (head && min_pts > 1) {
+                const uint32_t e = i + min_pts - 1;
+                keep = (e >= i) && (e < n) && (keys[e] == k);
+            }
+            cnt += keep ? 1u : 0u;
+        }
+    }
+    const uint32_t tot = block_sum_u32(cnt, lds);
+    if (threadIdx.x == 0) {
+        counts[blockIdx.x] = tot;
+        // Large frames only. One 128-byte line per group: same-line atomic requests serialise.
+        if (group_counts && tot) atomicAdd(&group_counts[(blockIdx.x / CM_SEG_GROUP) * 32], tot);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K3: kept voxels per sorted tile (published), gather, segmented centroid reduction, threshold,
 // compaction.
 // Thread t owns 8 consecutive sorted items; runs closed inside a thread are summed sequentially in
@@ -635,18 +676,6 @@ __device__ __forceinline__ Pt gather_point(const SensorLds* __restrict__ tab, ui
     return o;
 }
 
-// Spin (bounded) until another workgroup of this launch has published its word. The word carries
-// its own flag (bit 31), so no ordering with other data is needed; relaxed agent-scope accesses go
-// past the non-coherent L1 (guide: data-is-the-flag granules).
-__device__ __forceinline__ uint32_t wait_published(uint32_t* p, uint32_t* err) {
-    for (uint32_t spins = 0;; ++spins) {
-        const uint32_t v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v & 0x80000000u) return v & 0x7FFFFFFFu;
-        if (spins > (1u << 20)) { *err = 1u; return 0u; }
-        __builtin_amdgcn_s_sleep(2);
-    }
-}
-
 __global__ __launch_bounds__(CM_BLOCK) void k_seg_reduce(const CmFrameDev* __restrict__ fd,
                                                          CmFrameState* __restrict__ st,
                                                          CmFrameState* __restrict__ st_next,
@@ -654,7 +683,8 @@ __global__ __launch_bounds__(CM_BLOCK) void k_seg_reduce(const CmFrameDev* __res
                                                          const uint32_t* __restrict__ vals_a,
                                                          const uint32_t* __restrict__ keys_b,
                                                          const uint32_t* __restrict__ vals_b,
-                                                         uint32_t* __restrict__ sync_words,
+                                                         const uint32_t* __restrict__ counts,
+                                                         const uint32_t* __restrict__ group_counts,
                                                          float4* __restrict__ out,
                                                          uint32_t* __restrict__ out_key,
                                                          uint32_t* __restrict__ out_cnt) {
@@ -665,10 +695,6 @@ __global__ __launch_bounds__(CM_BLOCK) void k_seg_reduce(const CmFrameDev* __res
     __shared__ float s_ext[CM_WAVES][4];
     __shared__ uint32_t s_extc[CM_WAVES];
     __shared__ uint32_t lds[CM_WAVES];
-    __shared__ uint32_t s_tile;
-    // Tiles are handed out in arrival order, so every tile with a smaller id is already running
-    // (its published count is never waited for in vain, whatever the dispatch order).
-    if (threadIdx.x == 0) s_tile = atomicAdd(&sync_words[0], 1u);
     const uint32_t n_sensors = fd->n_sensors;
     if (threadIdx.x < n_sensors) {
         const CmSensorDev& g = fd->s[threadIdx.x];
@@ -678,7 +704,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_seg_reduce(const CmFrameDev* __res
         for (int k = 0; k < 12; ++k) t.m[k] = g.m[k];
     }
     __syncthreads();
-    const uint32_t tile = s_tile;
+    const uint32_t tile = blockIdx.x;
     if (tile == 0 && st_next && threadIdx.x < sizeof(CmFrameState) / 4)
         reinterpret_cast<uint32_t*>(st_next)[threadIdx.x] = 0;          // next frame starts from zero
     if (st->status != CM_DEV_OK) return;
@@ -726,9 +752,8 @@ __global__ __launch_bounds__(CM_BLOCK) void k_seg_reduce(const CmFrameDev* __res
     const uint32_t kext0 = (jext0 < n) ? keys[jext0] : 0u;
     const uint32_t vext0 = (jext0 < n) ? vals[jext0] : 0u;
 
-    // head flags; a run is kept iff it reaches min_points_per_voxel (A.4 step 7), i.e.
-    // keys[head + min_pts - 1] == key. `need`: items of runs longer than one point.
-    uint32_t heads = 0, live = 0, need = 0, nkeep_look = 0;
+    // head flags; `need`: items whose run can reach min_points_per_voxel (all, or runs of >= 2).
+    uint32_t heads = 0, live = 0, need = 0;
 #pragma unroll
     for (int j = 0; j < CM_SEG_ITEMS; ++j) {
         const uint32_t i = i0 + j;
@@ -738,24 +763,21 @@ __global__ __launch_bounds__(CM_BLOCK) void k_seg_reduce(const CmFrameDev* __res
             const bool head = (i == 0) || (pk != k[j]);
             const bool same_next = (j == CM_SEG_ITEMS - 1) ? (has_next && knext == k[j])
                                                            : (i + 1 < n && k[(j + 1) % CM_SEG_ITEMS] == k[j]);
-            if (head) {
-                heads |= 1u << j;
-                bool keep = true;
-                if (min_pts == 2) keep = same_next;
-                else if (min_pts > 2) {
-                    const uint32_t e = i + min_pts - 1;
-                    keep = (e >= i) && (e < n) && (keys[e] == k[j]);
-                }
-                nkeep_look += keep ? 1u : 0u;
-            }
+            if (head) heads |= 1u << j;
             if (min_pts <= 1 || !head || same_next) need |= 1u << j;
         }
     }
-    // Publish this tile's kept-voxel count right away; the output offset is summed much later.
-    const uint32_t tile_keep = block_sum_u32(nkeep_look, lds);
-    if (threadIdx.x == 0)
-        __hip_atomic_store(&sync_words[CM_SYNC_HEADER + tile], tile_keep | 0x80000000u, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+    // Output offset of this tile: kept voxels of the earlier groups + of the earlier tiles of its
+    // own group (k_seg_count); loads issued here, summed after the gather.
+    uint32_t before = 0;
+    if (group_counts) {
+        const uint32_t g = tile / CM_SEG_GROUP;
+        for (uint32_t q = threadIdx.x; q < g; q += CM_BLOCK) before += group_counts[q * 32];
+        const uint32_t t = g * CM_SEG_GROUP + threadIdx.x;      // CM_SEG_GROUP == CM_BLOCK
+        if (t < tile) before += counts[t];
+    } else {
+        for (uint32_t t = threadIdx.x; t < tile; t += CM_BLOCK) before += counts[t];
+    }
 
     // gather + transform (only points whose run can survive the threshold)
     Pt p[CM_SEG_ITEMS];
@@ -884,13 +906,8 @@ __global__ __launch_bounds__(CM_BLOCK) void k_seg_reduce(const CmFrameDev* __res
 #pragma unroll
     for (int j = 0; j < CM_SEG_ITEMS; ++j)
         if ((fmask >> j & 1u) && fin[j].c >= min_pts) ++nkeep;
-    // Output offset of this tile = kept voxels of every earlier tile (published long ago).
-    uint32_t before = 0, spin_err = 0;
-    for (uint32_t t = threadIdx.x; t < tile; t += CM_BLOCK)
-        before += wait_published(&sync_words[CM_SYNC_HEADER + t], &spin_err);
     const uint32_t tile_off = block_sum_u32(before, lds);
-    if (spin_err) st->err = 1u;
-    if (tile == n_tiles - 1 && threadIdx.x == 0) st->n_out = tile_off + tile_keep;
+    if (tile == n_tiles - 1 && threadIdx.x == 0) st->n_out = tile_off + counts[tile];
     uint32_t tot;
     uint32_t slot = tile_off + block_excl_scan_u32(nkeep, lds, &tot);
 #pragma unroll
@@ -998,10 +1015,10 @@ void cmk_minmax(hipStream_t s, const CmFrameDev* fd, float* partials, uint32_t n
 }
 void cmk_keys(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* keys, uint32_t* hist,
               uint32_t* grp_acc, uint32_t* grp_clear_a, uint32_t* grp_clear_b, uint32_t n_group_words,
-              uint32_t n_clear_a_words, uint32_t* sync_words, const float* partials, uint32_t n_partials,
-              int from_crop, uint32_t n_tiles) {
+              uint32_t n_clear_a_words, uint32_t* seg_groups, uint32_t n_seg_groups, const float* partials,
+              uint32_t n_partials, int from_crop, uint32_t n_tiles) {
     CM_LAUNCH(k_keys, n_tiles, CM_BLOCK, s, fd, st, keys, hist, grp_acc, grp_clear_a, grp_clear_b,
-              n_group_words, n_clear_a_words, sync_words, partials, n_partials, from_crop);
+              n_group_words, n_clear_a_words, seg_groups, n_seg_groups, partials, n_partials, from_crop);
 }
 void cmk_hist(hipStream_t s, const CmFrameState* st, const uint32_t* keys, uint32_t* hist, uint32_t* grp,
               uint32_t pass, uint32_t n_tiles) {
@@ -1022,12 +1039,16 @@ void cmk_scatter(hipStream_t s, CmFrameState* st, const uint32_t* keys_in, const
         CM_LAUNCH(k_scatter<false>, n_tiles, CM_BLOCK, s, st, keys_in, vals_in, keys_out, vals_out, hist, grp,
                   totals, pass, n_groups, n_padded);
 }
+void cmk_seg_count(hipStream_t s, const CmFrameState* st, const uint32_t* keys_a, const uint32_t* keys_b,
+                   uint32_t* counts, uint32_t* group_counts, uint32_t min_pts, uint32_t n_seg_tiles) {
+    CM_LAUNCH(k_seg_count, n_seg_tiles, CM_BLOCK, s, st, keys_a, keys_b, counts, group_counts, min_pts);
+}
 void cmk_seg_reduce(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next,
                     const uint32_t* keys_a, const uint32_t* vals_a, const uint32_t* keys_b,
-                    const uint32_t* vals_b, uint32_t* sync_words, void* out, uint32_t* out_key,
-                    uint32_t* out_cnt, uint32_t n_seg_tiles) {
+                    const uint32_t* vals_b, const uint32_t* counts, const uint32_t* group_counts, void* out,
+                    uint32_t* out_key, uint32_t* out_cnt, uint32_t n_seg_tiles) {
     CM_LAUNCH(k_seg_reduce, n_seg_tiles, CM_BLOCK, s, fd, st, st_next, keys_a, vals_a, keys_b, vals_b,
-              sync_words, reinterpret_cast<float4*>(out), out_key, out_cnt);
+              counts, group_counts, reinterpret_cast<float4*>(out), out_key, out_cnt);
 }
 void cmk_merged(hipStream_t s, const CmFrameDev* fd, uint32_t* tile_counts, uint32_t* total, void* out,
                 uint32_t n_tiles) {
