@@ -133,7 +133,8 @@ def main():
         "config": {"workload": workload, "points_per_frame": n_in, "voxels_out": n_out,
                    "min_points_per_voxel": args.min_pts, "sharding": f"frame-sharded x{world}, no collective",
                    "inputs": "resident in HBM (16-byte XYZI records)",
-                   "gpu_ms_per_step_events": gpu_ms_region / args.steps},
+                   "gpu_ms_per_step_events": gpu_ms_region / args.steps,
+                   "radix_ranking": "lds-add (device probe passed)" if res.path_flags & 1 else "ballot-match"},
     }
 
     if rank == 0:

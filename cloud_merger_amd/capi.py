@@ -49,7 +49,7 @@ class Result(C.Structure):
                 ("min_b", C.c_int32 * 3), ("max_b", C.c_int32 * 3), ("div_b", C.c_int32 * 3),
                 ("min_p", C.c_float * 3), ("max_p", C.c_float * 3),
                 ("bounds_from_crop", C.c_uint32), ("key_bits", C.c_uint32), ("sort_passes", C.c_uint32),
-                ("_reserved", C.c_uint32), ("device_ms", C.c_float)]
+                ("path_flags", C.c_uint32), ("device_ms", C.c_float)]
 
 
 class StageTimes(C.Structure):

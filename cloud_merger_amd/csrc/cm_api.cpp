@@ -16,6 +16,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -52,6 +53,7 @@ struct cm_ctx {
     uint32_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr;
     uint32_t *hist = nullptr, *grp = nullptr, *totals = nullptr, *seg_counts = nullptr, *seg_tile_counts = nullptr, *seg_groups = nullptr;
     uint32_t cap_groups = 0, frame_seq = 0;
+    bool lds_rank = false;               // k_probe_lds_order found lane-ordered LDS adds on this device
     float* partials = nullptr;
     uint32_t *out_key = nullptr, *out_cnt = nullptr, *merged_total = nullptr;
     void* out = nullptr;
@@ -324,7 +326,7 @@ int enqueue(cm_ctx* c, const cm_params* p) {
         if (big) { prof_mark(c, "k_gscan"); cmk_gscan(st, state, grp, c->totals, pass, n_groups); }
         prof_mark(c, "k_scatter");
         cmk_scatter(st, state, kin, vin, kout, vout, c->hist, grp, big ? c->totals : nullptr, pass, nt,
-                    n_groups, f.n_padded);
+                    n_groups, f.n_padded, c->lds_rank);
     }
     prof_mark(c, "k_seg_count");
     uint32_t* seg_groups = nseg > CM_SEG_DIRECT_TILES ? c->seg_groups : nullptr;
@@ -366,6 +368,7 @@ int wait_frame(cm_ctx* c, cm_result* res) {
         }
         r.key_bits = h.key_bits;
         r.sort_passes = h.n_passes;
+        r.path_flags = c->lds_rank ? 1u : 0u;
         if (h.status == CM_OK) {
             r.n_merged = h.n_valid;
             r.n_out = h.n_out;
@@ -466,6 +469,23 @@ int cm_create(cm_ctx** out, int device, const cm_limits* lim) {
     ok = ok && hipMemset(c->d_state[0], 0, sizeof(CmFrameState)) == hipSuccess;
     ok = ok && hipMemset(c->d_state[1], 0, sizeof(CmFrameState)) == hipSuccess;
     ok = ok && hipDeviceSynchronize() == hipSuccess;
+    if (ok) {
+        // Probe the device once: lane-ordered returning LDS adds allow the cheap stable ranking.
+        // CM_LDS_RANK=0 forces the ballot-match ranking, CM_LDS_RANK=1 skips the probe.
+        const char* env = getenv("CM_LDS_RANK");
+        if (env && env[0] == '0') c->lds_rank = false;
+        else if (env && env[0] == '1') c->lds_rank = true;
+        else {
+            uint32_t violations = 1;
+            ok = hipMemset(c->merged_total, 0, 4) == hipSuccess;
+            if (ok) {
+                cmk_probe_lds_order(c->stream, c->merged_total, 64);
+                ok = hipMemcpyAsync(&violations, c->merged_total, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                     hipStreamSynchronize(c->stream) == hipSuccess;
+            }
+            c->lds_rank = ok && violations == 0;
+        }
+    }
     if (!ok) {
         free_all(c);
         delete c;

@@ -18,7 +18,8 @@ void cmk_gscan(hipStream_t s, const CmFrameState* st, uint32_t* grp, uint32_t* t
 void cmk_scatter(hipStream_t s, CmFrameState* st, const uint32_t* keys_in, const uint32_t* vals_in,
                  uint32_t* keys_out, uint32_t* vals_out, const uint32_t* hist, const uint32_t* grp,
                  const uint32_t* totals, uint32_t pass, uint32_t n_tiles, uint32_t n_groups,
-                 uint32_t n_padded);
+                 uint32_t n_padded, bool lds_rank);
+void cmk_probe_lds_order(hipStream_t s, uint32_t* violations, uint32_t rounds);
 void cmk_seg_count(hipStream_t s, const CmFrameState* st, const uint32_t* keys_a, const uint32_t* keys_b,
                    uint32_t* counts, uint32_t* group_counts, uint32_t min_pts, uint32_t n_seg_tiles);
 void cmk_seg_reduce(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next,

@@ -460,9 +460,48 @@ __device__ __forceinline__ unsigned long long match_digit(uint32_t digit, bool v
     return mask;
 }
 
+// Device probe: does a returning LDS add hand lanes that hit the same address their old values in
+// lane order (and successive instructions of a wave in program order)? Not an architectural
+// promise, so the stable ranking built on it (k_scatter<*, true>) is only selected when this
+// probe finds no violation on the device at hand; otherwise the ballot-match ranking is used.
+__global__ __launch_bounds__(CM_BLOCK) void k_probe_lds_order(uint32_t* __restrict__ violations, uint32_t rounds) {
+    __shared__ uint32_t cnt[CM_WAVES][CM_RADIX];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t bad = 0;
+    uint32_t x = 0x9E3779B9u * (blockIdx.x * CM_BLOCK + threadIdx.x + 1);
+    for (uint32_t it = 0; it < rounds; ++it) {
+        for (int q = 0; q < CM_WAVES; ++q) cnt[q][threadIdx.x] = 0;
+        __syncthreads();
+        // four back-to-back DS instructions; digits drawn from 1, 2, 7 or 256 values
+        const uint32_t spread = (it & 3u) == 0 ? 1u : (it & 3u) == 1 ? 2u : (it & 3u) == 2 ? 7u : 256u;
+        uint32_t dg[4], got[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+            dg[r] = (x >> 8) % spread;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) got[r] = atomicAdd(&cnt[w][dg[r]], 1u);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            // lanes below me with my digit in instruction r + every lane of the earlier instructions
+            uint32_t e = __popcll(match_digit(dg[r], true) & lt);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < r)
+                    for (int l = 0; l < 64; ++l) e += (static_cast<uint32_t>(__shfl(static_cast<int>(dg[q]), l)) == dg[r]) ? 1u : 0u;
+            }
+            bad += (got[r] != e) ? 1u : 0u;
+        }
+        __syncthreads();
+    }
+    if (bad) atomicAdd(violations, bad);
+}
+
 // Stable scatter of one tile by one digit. FIRST: values are the padded global indices and
 // CM_INVALID_KEY slots are dropped (this is where the concatenated cloud gets compacted).
-template <bool FIRST>
+template <bool FIRST, bool LDS_RANK>
 __global__ __launch_bounds__(CM_BLOCK, 4) void k_scatter(CmFrameState* __restrict__ st,
                                                       const uint32_t* __restrict__ keys_in,
                                                       const uint32_t* __restrict__ vals_in,
@@ -533,20 +572,31 @@ __global__ __launch_bounds__(CM_BLOCK, 4) void k_scatter(CmFrameState* __restric
     __syncthreads();
 
     // Rank inside the wave, rounds in order, lanes in order: stable.
-    volatile uint32_t* wh = whist[w];
-    const unsigned long long lt = (1ull << lane) - 1ull;
     uint32_t rank[CM_ITEMS];
+    if (LDS_RANK) {
+        // One returning LDS add per item. Only used after k_probe_lds_order has shown, on this
+        // device, that same-address lanes of one DS instruction are served in lane order.
 #pragma unroll
-    for (int r = 0; r < CM_ITEMS; ++r) {
-        const bool valid = FIRST ? (key[r] != CM_INVALID_KEY) : (first + r * 64 < n);
-        const uint32_t digit = (key[r] >> shift) & (CM_RADIX - 1);
-        const unsigned long long peers = match_digit(digit, valid);
-        const uint32_t below = __popcll(peers & lt);
-        const uint32_t base = wh[digit];
-        __builtin_amdgcn_wave_barrier();
-        if (valid && below == 0) wh[digit] = base + __popcll(peers);
-        __builtin_amdgcn_wave_barrier();
-        rank[r] = base + below;
+        for (int r = 0; r < CM_ITEMS; ++r) {
+            const bool valid = FIRST ? (key[r] != CM_INVALID_KEY) : (first + r * 64 < n);
+            const uint32_t digit = (key[r] >> shift) & (CM_RADIX - 1);
+            rank[r] = valid ? atomicAdd(&whist[w][digit], 1u) : 0u;
+        }
+    } else {
+        volatile uint32_t* wh = whist[w];
+        const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int r = 0; r < CM_ITEMS; ++r) {
+            const bool valid = FIRST ? (key[r] != CM_INVALID_KEY) : (first + r * 64 < n);
+            const uint32_t digit = (key[r] >> shift) & (CM_RADIX - 1);
+            const unsigned long long peers = match_digit(digit, valid);
+            const uint32_t below = __popcll(peers & lt);
+            const uint32_t base = wh[digit];
+            __builtin_amdgcn_wave_barrier();
+            if (valid && below == 0) wh[digit] = base + __popcll(peers);
+            __builtin_amdgcn_wave_barrier();
+            rank[r] = base + below;
+        }
     }
     __syncthreads();
 
@@ -1031,13 +1081,25 @@ void cmk_gscan(hipStream_t s, const CmFrameState* st, uint32_t* grp, uint32_t* t
 void cmk_scatter(hipStream_t s, CmFrameState* st, const uint32_t* keys_in, const uint32_t* vals_in,
                  uint32_t* keys_out, uint32_t* vals_out, const uint32_t* hist, const uint32_t* grp,
                  const uint32_t* totals, uint32_t pass, uint32_t n_tiles, uint32_t n_groups,
-                 uint32_t n_padded) {
-    if (pass == 0)
-        CM_LAUNCH(k_scatter<true>, n_tiles, CM_BLOCK, s, st, keys_in, vals_in, keys_out, vals_out, hist, grp,
-                  totals, pass, n_groups, n_padded);
-    else
-        CM_LAUNCH(k_scatter<false>, n_tiles, CM_BLOCK, s, st, keys_in, vals_in, keys_out, vals_out, hist, grp,
-                  totals, pass, n_groups, n_padded);
+                 uint32_t n_padded, bool lds_rank) {
+    if (pass == 0) {
+        if (lds_rank)
+            CM_LAUNCH((k_scatter<true, true>), n_tiles, CM_BLOCK, s, st, keys_in, vals_in, keys_out, vals_out,
+                      hist, grp, totals, pass, n_groups, n_padded);
+        else
+            CM_LAUNCH((k_scatter<true, false>), n_tiles, CM_BLOCK, s, st, keys_in, vals_in, keys_out, vals_out,
+                      hist, grp, totals, pass, n_groups, n_padded);
+    } else {
+        if (lds_rank)
+            CM_LAUNCH((k_scatter<false, true>), n_tiles, CM_BLOCK, s, st, keys_in, vals_in, keys_out, vals_out,
+                      hist, grp, totals, pass, n_groups, n_padded);
+        else
+            CM_LAUNCH((k_scatter<false, false>), n_tiles, CM_BLOCK, s, st, keys_in, vals_in, keys_out, vals_out,
+                      hist, grp, totals, pass, n_groups, n_padded);
+    }
+}
+void cmk_probe_lds_order(hipStream_t s, uint32_t* violations, uint32_t rounds) {
+    CM_LAUNCH(k_probe_lds_order, 512, CM_BLOCK, s, violations, rounds);
 }
 void cmk_seg_count(hipStream_t s, const CmFrameState* st, const uint32_t* keys_a, const uint32_t* keys_b,
                    uint32_t* counts, uint32_t* group_counts, uint32_t min_pts, uint32_t n_seg_tiles) {

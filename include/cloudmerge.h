@@ -88,7 +88,8 @@ typedef struct cm_result {
                                       order; the data min/max pass was skipped) */
     uint32_t key_bits;             /* bits of the linear voxel index */
     uint32_t sort_passes;          /* 8-bit radix passes run */
-    uint32_t _reserved;
+    uint32_t path_flags;           /* bit 0: radix ranking by lane-ordered LDS adds (the device probe at
+                                      cm_create passed); otherwise ballot matching */
     float device_ms;               /* first kernel start -> last kernel end (CM_FLAG_PROFILE) */
 } cm_result;
 

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for m in $MODES; do
-  for mp in 2 0; do
+  for mp in 2; do
   CM_EXP=$m rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/exp_${m}_${mp} -- python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline --min-pts $mp > /dev/null 2> gpurun_out/exp.err
   f=$(find gpurun_out/exp_${m}_${mp} -name "*kernel_stats.csv" | head -1)
   python3 - "$f" "$m" "$mp" <<'PY'
