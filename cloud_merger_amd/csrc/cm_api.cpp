@@ -63,7 +63,8 @@ struct cm_ctx {
     bool frame_uploaded_valid = false;
     CmFrameState* d_state[2] = {nullptr, nullptr};
     int cur = 0;
-    CmFrameState* h_state = nullptr;     // pinned
+    CmFrameState* h_state = nullptr;     // pinned, written by the last kernel of a frame
+    uint32_t* h_state_dev = nullptr;     // device view of h_state
     hipEvent_t ev_done = nullptr;
 
     std::mutex merge_mu;
@@ -332,12 +333,11 @@ int enqueue(cm_ctx* c, const cm_params* p) {
     uint32_t* seg_groups = nseg > CM_SEG_DIRECT_TILES ? c->seg_groups : nullptr;
     cmk_seg_count(st, state, c->keys_a, c->keys_b, c->seg_tile_counts, seg_groups, f.min_pts, nseg);
     prof_mark(c, "k_seg_reduce");
-    cmk_seg_reduce(st, c->d_frame, state, state_next, c->keys_a, c->vals_a, c->keys_b, c->vals_b,
-                   c->seg_tile_counts, seg_groups, c->out, c->out_key, c->out_cnt, nseg);
+    cmk_seg_reduce(st, c->d_frame, state, state_next, c->h_state_dev, c->keys_a, c->vals_a, c->keys_b,
+                   c->vals_b, c->seg_tile_counts, seg_groups, c->out, c->out_key, c->out_cnt, nseg);
     prof_mark(c, "end");
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(c->h_state, state, sizeof(CmFrameState), hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipEventRecord(c->ev_done, st));
+    HIP_TRY(c, hipEventRecord(c->ev_done, st));     // k_seg_reduce wrote the state record to h_state
     c->cur ^= 1;
     c->in_flight.store(true);
     c->pending = true;
@@ -464,6 +464,7 @@ int cm_create(cm_ctx** out, int device, const cm_limits* lim) {
     ok = ok && A(reinterpret_cast<void**>(&c->d_state[0]), sizeof(CmFrameState));
     ok = ok && A(reinterpret_cast<void**>(&c->d_state[1]), sizeof(CmFrameState));
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_state), sizeof(CmFrameState), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_state_dev), c->h_state, 0) == hipSuccess;
     for (uint32_t s = 0; ok && s < c->max_sensors; ++s)
         ok = hipStreamCreateWithFlags(&c->slots[s].copy_stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipMemset(c->d_state[0], 0, sizeof(CmFrameState)) == hipSuccess;

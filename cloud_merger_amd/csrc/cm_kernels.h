@@ -23,8 +23,9 @@ void cmk_probe_lds_order(hipStream_t s, uint32_t* violations, uint32_t rounds);
 void cmk_seg_count(hipStream_t s, const CmFrameState* st, const uint32_t* keys_a, const uint32_t* keys_b,
                    uint32_t* counts, uint32_t* group_counts, uint32_t min_pts, uint32_t n_seg_tiles);
 void cmk_seg_reduce(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next,
-                    const uint32_t* keys_a, const uint32_t* vals_a, const uint32_t* keys_b,
-                    const uint32_t* vals_b, const uint32_t* counts, const uint32_t* group_counts, void* out,
-                    uint32_t* out_key, uint32_t* out_cnt, uint32_t n_seg_tiles);
+                    uint32_t* host_state, const uint32_t* keys_a, const uint32_t* vals_a,
+                    const uint32_t* keys_b, const uint32_t* vals_b, const uint32_t* counts,
+                    const uint32_t* group_counts, void* out, uint32_t* out_key, uint32_t* out_cnt,
+                    uint32_t n_seg_tiles);
 void cmk_merged(hipStream_t s, const CmFrameDev* fd, uint32_t* tile_counts, uint32_t* total, void* out,
                 uint32_t n_tiles);

@@ -17,6 +17,7 @@
 // semantics in SURVEY.md Appendix A. Every fp32 operation that decides occupancy uses the _rn
 // intrinsics so it is rounded once, in the reference's order, never contracted into an FMA.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "cm_device.h"
@@ -726,9 +727,22 @@ __device__ __forceinline__ Pt gather_point(const SensorLds* __restrict__ tab, ui
     return o;
 }
 
+// The workgroup that knows the frame's final numbers writes the whole state record straight into
+// pinned host memory (visible to the host when the kernel completes): no copy after the frame.
+__device__ __forceinline__ void report_state(uint32_t* __restrict__ host, const CmFrameState* __restrict__ st,
+                                             int status, uint32_t n_out) {
+    if (threadIdx.x < sizeof(CmFrameState) / 4) {
+        uint32_t wv = reinterpret_cast<const uint32_t*>(st)[threadIdx.x];
+        if (threadIdx.x == offsetof(CmFrameState, status) / 4) wv = static_cast<uint32_t>(status);
+        if (threadIdx.x == offsetof(CmFrameState, n_out) / 4) wv = n_out;
+        host[threadIdx.x] = wv;
+    }
+}
+
 __global__ __launch_bounds__(CM_BLOCK) void k_seg_reduce(const CmFrameDev* __restrict__ fd,
                                                          CmFrameState* __restrict__ st,
                                                          CmFrameState* __restrict__ st_next,
+                                                         uint32_t* __restrict__ host_state,
                                                          const uint32_t* __restrict__ keys_a,
                                                          const uint32_t* __restrict__ vals_a,
                                                          const uint32_t* __restrict__ keys_b,
@@ -757,10 +771,13 @@ __global__ __launch_bounds__(CM_BLOCK) void k_seg_reduce(const CmFrameDev* __res
     const uint32_t tile = blockIdx.x;
     if (tile == 0 && st_next && threadIdx.x < sizeof(CmFrameState) / 4)
         reinterpret_cast<uint32_t*>(st_next)[threadIdx.x] = 0;          // next frame starts from zero
-    if (st->status != CM_DEV_OK) return;
+    if (st->status != CM_DEV_OK) {
+        if (tile == 0) report_state(host_state, st, st->status, 0u);
+        return;
+    }
     const uint32_t n = st->n_valid;
     if (n == 0) {
-        if (tile == 0 && threadIdx.x == 0) { st->status = CM_DEV_EMPTY; st->n_out = 0; }
+        if (tile == 0) report_state(host_state, st, CM_DEV_EMPTY, 0u);
         return;
     }
     const uint32_t base = tile * CM_SEG_TILE;
@@ -957,7 +974,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_seg_reduce(const CmFrameDev* __res
     for (int j = 0; j < CM_SEG_ITEMS; ++j)
         if ((fmask >> j & 1u) && fin[j].c >= min_pts) ++nkeep;
     const uint32_t tile_off = block_sum_u32(before, lds);
-    if (tile == n_tiles - 1 && threadIdx.x == 0) st->n_out = tile_off + counts[tile];
+    if (tile == n_tiles - 1) report_state(host_state, st, CM_DEV_OK, tile_off + counts[tile]);
     uint32_t tot;
     uint32_t slot = tile_off + block_excl_scan_u32(nkeep, lds, &tot);
 #pragma unroll
@@ -1106,11 +1123,12 @@ void cmk_seg_count(hipStream_t s, const CmFrameState* st, const uint32_t* keys_a
     CM_LAUNCH(k_seg_count, n_seg_tiles, CM_BLOCK, s, st, keys_a, keys_b, counts, group_counts, min_pts);
 }
 void cmk_seg_reduce(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next,
-                    const uint32_t* keys_a, const uint32_t* vals_a, const uint32_t* keys_b,
-                    const uint32_t* vals_b, const uint32_t* counts, const uint32_t* group_counts, void* out,
-                    uint32_t* out_key, uint32_t* out_cnt, uint32_t n_seg_tiles) {
-    CM_LAUNCH(k_seg_reduce, n_seg_tiles, CM_BLOCK, s, fd, st, st_next, keys_a, vals_a, keys_b, vals_b,
-              counts, group_counts, reinterpret_cast<float4*>(out), out_key, out_cnt);
+                    uint32_t* host_state, const uint32_t* keys_a, const uint32_t* vals_a,
+                    const uint32_t* keys_b, const uint32_t* vals_b, const uint32_t* counts,
+                    const uint32_t* group_counts, void* out, uint32_t* out_key, uint32_t* out_cnt,
+                    uint32_t n_seg_tiles) {
+    CM_LAUNCH(k_seg_reduce, n_seg_tiles, CM_BLOCK, s, fd, st, st_next, host_state, keys_a, vals_a, keys_b,
+              vals_b, counts, group_counts, reinterpret_cast<float4*>(out), out_key, out_cnt);
 }
 void cmk_merged(hipStream_t s, const CmFrameDev* fd, uint32_t* tile_counts, uint32_t* total, void* out,
                 uint32_t n_tiles) {
