@@ -1,0 +1,117 @@
+// host_tests.cpp — CPU-side checks of the host shell (no GPU needed): PointCloud2 field lookup,
+// PCD round trip, the reference's literals in reference_config(), and that the node fails loudly
+// (no fallback) when no MI355X is present. Exit code 0 = all passed. Run by tests/test_host_shell.py.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "merger_node.hpp"
+#include "pcd_io.hpp"
+
+using namespace cloudmerge;
+
+static int failures = 0;
+#define CHECK(cond) do { if (!(cond)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); ++failures; } } while (0)
+
+static void test_find_xyzi() {
+    PointCloud2 m = make_pcl_xyzi_message(3);
+    XyziLayout l = find_xyzi(m);
+    CHECK(l.ok && l.off_x == 0 && l.off_y == 4 && l.off_z == 8 && l.off_i == 16 && m.point_step == 32);
+    PointCloud2 c = make_xyzi16_message(3);
+    l = find_xyzi(c);
+    CHECK(l.ok && l.off_i == 12 && c.point_step == 16);
+    c.fields.pop_back();                                   // no intensity: treated as 0
+    l = find_xyzi(c);
+    CHECK(l.ok && l.off_i == 0xFFFFFFFFu);
+    c.fields[1].datatype = PointField::FLOAT64;
+    CHECK(!find_xyzi(c).ok);
+    PointCloud2 shortmsg = make_xyzi16_message(3);
+    shortmsg.data.resize(10);
+    CHECK(!find_xyzi(shortmsg).ok);
+    // Velodyne-like layout with trailing ring/time fields
+    PointCloud2 v;
+    v.width = 2; v.height = 1; v.point_step = 22; v.row_step = 44; v.data.resize(44);
+    v.fields = {{"x", 0, PointField::FLOAT32, 1}, {"y", 4, PointField::FLOAT32, 1}, {"z", 8, PointField::FLOAT32, 1},
+                {"intensity", 12, PointField::FLOAT32, 1}, {"ring", 16, PointField::UINT16, 1}, {"time", 18, PointField::FLOAT32, 1}};
+    l = find_xyzi(v);
+    CHECK(l.ok && l.off_i == 12);
+}
+
+static void test_pcd_roundtrip(const char* tmpdir) {
+    PointCloud2 m = make_pcl_xyzi_message(5);
+    for (int i = 0; i < 5; ++i) {
+        float rec[8] = {i + 0.25f, -i * 2.0f, i * 0.5f, 1.0f, 10.0f * i, 0, 0, 0};
+        std::memcpy(m.data.data() + i * 32, rec, 32);
+    }
+    const std::string path = std::string(tmpdir) + "/roundtrip.pcd";
+    std::string err;
+    CHECK(write_pcd(path, m, &err));
+    PointCloud2 r;
+    CHECK(read_pcd(path, &r, &err));
+    CHECK(r.num_points() == 5 && r.point_step == 16 && r.fields.size() == 4);
+    const XyziLayout l = find_xyzi(r);
+    CHECK(l.ok && l.off_i == 12);
+    for (int i = 0; i < 5 && r.data.size() >= 80; ++i) {
+        float rec[4];
+        std::memcpy(rec, r.data.data() + i * 16, 16);
+        CHECK(rec[0] == i + 0.25f && rec[1] == -i * 2.0f && rec[2] == i * 0.5f && rec[3] == 10.0f * i);
+    }
+    // ascii variant
+    const std::string apath = std::string(tmpdir) + "/ascii.pcd";
+    FILE* f = std::fopen(apath.c_str(), "w");
+    std::fprintf(f, "# .PCD v0.7\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 2\nHEIGHT 1\n"
+                    "VIEWPOINT 0 0 0 1 0 0 0\nPOINTS 2\nDATA ascii\n1.5 2.5 3.5\n-1 -2 nan\n");
+    std::fclose(f);
+    PointCloud2 a;
+    CHECK(read_pcd(apath, &a, &err));
+    CHECK(a.num_points() == 2 && a.point_step == 12 && find_xyzi(a).off_i == 0xFFFFFFFFu);
+    float z1;
+    std::memcpy(&z1, a.data.data() + 12 + 8, 4);
+    CHECK(std::isnan(z1));
+    CHECK(!read_pcd(std::string(tmpdir) + "/missing.pcd", &a, &err));
+}
+
+static void test_reference_config() {
+    const NodeConfig c = reference_config();
+    CHECK(c.sensors.size() == 6);
+    CHECK(c.sensors[0].topic == "/velodyne/front_right/velodyne_points" && c.sensors[0].frame == "/velodyne_front_right");
+    CHECK(c.sensors[5].topic == "/livoxfront/livox/lidar" && c.sensors[5].frame == "/livox_front");
+    CHECK(c.sensors[4].name == "top_middle" && !c.sensors[4].required);      // :136
+    int required = 0;
+    for (const auto& s : c.sensors) required += s.required ? 1 : 0;
+    CHECK(required == 5);                                                     // :134
+    CHECK(c.voxel_topic == "/points_voxel" && c.base_frame == "base_footprint" && c.rate_hz == 10.0);
+    CHECK(c.params.leaf[0] == 0.1f && c.params.min_points_per_voxel == 2 && c.params.downsample_all_data == 1);
+    CHECK(c.params.crop_enable == 1);
+    CHECK(c.params.crop_min[0] == -15.0f && c.params.crop_max[0] == 60.0f);
+    CHECK(c.params.crop_min[1] == -5.0f && c.params.crop_max[1] == 5.0f);
+    CHECK(c.params.crop_min[2] == -0.5f && c.params.crop_max[2] == 3.0f);
+}
+
+static void test_node_without_gpu_fails_loudly(bool expect_gpu) {
+    NodeConfig c = reference_config();
+    c.max_points_total = 1000;
+    CloudMergerNode node(c);
+    if (expect_gpu) {
+        CHECK(node.ok());
+        CHECK(node.sensor_by_topic("/livoxfront/livox/lidar") == 5 && node.sensor_by_topic("/nope") == -1);
+        CHECK(!node.transforms_ready());
+        PointCloud2 m = make_xyzi16_message(4);
+        CHECK(node.on_cloud(0, m) == CM_NOT_READY);                        // transforms not looked up yet
+        CHECK(node.spin_once() == CM_NOT_READY);
+    } else {
+        CHECK(!node.ok() && !node.error().empty());
+        CHECK(node.spin_once() == CM_NO_DEVICE);
+    }
+}
+
+int main(int argc, char** argv) {
+    const char* tmpdir = argc > 1 ? argv[1] : "/tmp";
+    const bool expect_gpu = argc > 2 && std::strcmp(argv[2], "gpu") == 0;
+    test_find_xyzi();
+    test_pcd_roundtrip(tmpdir);
+    test_reference_config();
+    test_node_without_gpu_fails_loudly(expect_gpu);
+    std::printf("%s (%d failures)\n", failures ? "FAILED" : "ok", failures);
+    return failures ? 1 : 0;
+}

@@ -1,0 +1,121 @@
+// merger_node.cpp — see merger_node.hpp.
+#include "merger_node.hpp"
+
+#include <chrono>
+#include <thread>
+
+namespace cloudmerge {
+
+NodeConfig reference_config() {
+    NodeConfig c;
+    // Topics :520-525, TF frames :556-561, fuse order :137-142, gate :134-136.
+    c.sensors = {
+        {"front_right", "/velodyne/front_right/velodyne_points", "/velodyne_front_right", true},
+        {"front_left", "/velodyne/front_left/velodyne_points", "/velodyne_front_left", true},
+        {"rear_right", "/velodyne/rear_right/velodyne_points", "/velodyne_rear_right", true},
+        {"rear_left", "/velodyne/rear_left/velodyne_points", "/velodyne_rear_left", true},
+        {"top_middle", "/velodyne/top_middle/velodyne_points", "/velodyne_top_middle", false},
+        {"front_middle", "/livoxfront/livox/lidar", "/livox_front", true},
+    };
+    cm_params& p = c.params;
+    p.leaf[0] = p.leaf[1] = p.leaf[2] = 0.1f;       // voxel_size, Parameter.h:28
+    p.min_points_per_voxel = 2;                     // points_per_voxel, Parameter.h:27
+    p.downsample_all_data = 1;                      // :174
+    p.crop_enable = 1;                              // getROI, :20-40
+    const float roi_width = 10.0f, roi_length = 75.0f, roi_mid = 15.0f;   // Parameter.h:31-33
+    p.crop_min[0] = -roi_mid;        p.crop_max[0] = roi_length - roi_mid;
+    p.crop_min[1] = -roi_width / 2;  p.crop_max[1] = roi_width / 2;
+    p.crop_min[2] = -0.5f;           p.crop_max[2] = 3.0f;                 // Parameter.h:34-35
+    return c;
+}
+
+CloudMergerNode::CloudMergerNode(const NodeConfig& cfg) : cfg_(cfg), have_tf_(cfg.sensors.size()) {
+    for (auto& f : have_tf_) f.store(false);
+    if (cfg_.sensors.empty() || cfg_.sensors.size() > CM_MAX_SENSORS) {
+        error_ = "sensor count must be 1..CM_MAX_SENSORS";
+        return;
+    }
+    uint32_t mask = 0;
+    for (size_t s = 0; s < cfg_.sensors.size(); ++s)
+        if (cfg_.sensors[s].required) mask |= 1u << s;
+    cfg_.params.required_sensor_mask = mask;
+    cm_limits lim{};
+    lim.max_sensors = static_cast<uint32_t>(cfg_.sensors.size());
+    lim.flags = cfg_.flags;
+    lim.max_points_total = cfg_.max_points_total;
+    const int st = cm_create(&ctx_, cfg_.device, &lim);
+    if (st != CM_OK) {
+        ctx_ = nullptr;
+        error_ = std::string("cm_create: ") + cm_status_string(st);
+    }
+    clock_ = [] {
+        return static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(
+            std::chrono::system_clock::now().time_since_epoch()).count());
+    };
+}
+
+CloudMergerNode::~CloudMergerNode() {
+    if (ctx_) cm_destroy(ctx_);
+}
+
+int CloudMergerNode::sensor_by_topic(const std::string& topic) const {
+    for (size_t s = 0; s < cfg_.sensors.size(); ++s)
+        if (cfg_.sensors[s].topic == topic) return static_cast<int>(s);
+    return -1;
+}
+
+int CloudMergerNode::set_transform(size_t sensor, const double q[4], const double t[3]) {
+    if (!ctx_ || sensor >= cfg_.sensors.size()) return CM_BAD_ARG;
+    const int st = cm_set_sensor_transform(ctx_, static_cast<uint32_t>(sensor), q, t);
+    if (st == CM_OK) have_tf_[sensor].store(true);
+    return st;
+}
+
+bool CloudMergerNode::transforms_ready() const {
+    for (const auto& f : have_tf_)
+        if (!f.load()) return false;
+    return true;
+}
+
+int CloudMergerNode::on_cloud(size_t sensor, const PointCloud2& msg) {
+    if (!ctx_ || sensor >= cfg_.sensors.size()) return CM_BAD_ARG;
+    if (!transforms_ready()) return CM_NOT_READY;
+    const XyziLayout l = find_xyzi(msg);
+    if (!l.ok) { error_ = l.error; return CM_BAD_ARG; }
+    return cm_submit_cloud(ctx_, static_cast<uint32_t>(sensor), msg.data.data(),
+                           static_cast<uint32_t>(msg.num_points()), msg.point_step, l.off_x, l.off_y, l.off_z, l.off_i);
+}
+
+int CloudMergerNode::spin_once(cm_result* res) {
+    if (!ctx_) return CM_NO_DEVICE;
+    cm_result r{};
+    const int st = cm_merge_voxelize(ctx_, &cfg_.params, &r);      // fusePointclouds + voxelgrid
+    if (res) *res = r;
+    if (st == CM_NOT_READY) return st;                              // :575 — nothing fused this tick
+    if (st < 0) { error_ = cm_last_error(ctx_); return st; }
+    // publishPointcloud, voxel leg (:215-219): PCL layout, stamp = now, frame = base_footprint.
+    PointCloud2 msg = cfg_.publish_pcl_layout ? make_pcl_xyzi_message(r.n_out) : make_xyzi16_message(r.n_out);
+    if (st == CM_EMPTY_INPUT) { msg.width = 0; msg.height = 0; msg.row_step = 0; }   // A.4 step 1
+    if (r.n_out) {
+        const int cs = cm_result_copy(ctx_, msg.data.data(), r.n_out, msg.point_step);
+        if (cs != CM_OK) { error_ = cm_last_error(ctx_); return cs; }
+    }
+    msg.header.seq = seq_++;
+    msg.header.stamp_ns = clock_();
+    msg.header.frame_id = cfg_.base_frame;
+    if (publish_) publish_(cfg_.voxel_topic, msg);
+    frames_.fetch_add(1);
+    return st;
+}
+
+void CloudMergerNode::run(const std::atomic<bool>& stop) {
+    const auto period = std::chrono::duration<double>(1.0 / cfg_.rate_hz);
+    auto next = std::chrono::steady_clock::now();
+    while (!stop.load()) {
+        spin_once();
+        next += std::chrono::duration_cast<std::chrono::steady_clock::duration>(period);
+        std::this_thread::sleep_until(next);                        // loop_rate.sleep(), :583
+    }
+}
+
+}  // namespace cloudmerge

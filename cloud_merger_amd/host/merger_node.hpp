@@ -1,0 +1,91 @@
+// merger_node.hpp — C++ host shell with the reference node's surface: subscribe N sensor clouds,
+// publish one merged + voxel-filtered cloud. It re-creates the thin L3 layer of
+// pcl_preprocessing/src/pc_preprocessing_main.cpp (main :509-587, callbacks :318-508) on top of
+// the C-ABI in include/cloudmerge.h; every numeric step runs in libcloudmerge_hip.so.
+//
+// What is deliberately NOT here: ROI zoning, RANSAC ground removal and radius outlier removal
+// (:49-122, :184-192, :228-312) — SURVEY.md §8f "next" rows, outside the north-star path.
+#pragma once
+#include <atomic>
+#include <cstdint>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/cloudmerge.h"
+#include "pointcloud2.hpp"
+
+namespace cloudmerge {
+
+struct SensorSpec {
+    std::string name;       // "front_right", ...
+    std::string topic;      // input topic (:520-525)
+    std::string frame;      // TF frame looked up against the base frame (:556-561)
+    bool required = true;   // part of the fuse gate (:134); top_middle is not (:136)
+};
+
+struct NodeConfig {
+    std::vector<SensorSpec> sensors;
+    std::string base_frame = "base_footprint";     // frame_id of everything published (:206,:212,:218)
+    std::string voxel_topic = "/points_voxel";      // :518
+    double rate_hz = 10.0;                          // ros::Rate loop_rate(10) :527
+    cm_params params{};                             // Parameter.h:27-35 by default
+    uint64_t max_points_total = 4u << 20;
+    int device = 0;
+    uint32_t flags = 0;
+    bool publish_pcl_layout = true;                 // 32-byte pcl::PointXYZI records like pcl::toROSMsg
+};
+
+// The reference's literals: six sensors in fuse order fr, fl, rr, rl, tm, livox (:137-142), ROI
+// crop (Parameter.h:31-35), leaf 0.1 m, min 2 points per voxel (Parameter.h:27-28).
+NodeConfig reference_config();
+
+class CloudMergerNode {
+public:
+    using Publisher = std::function<void(const std::string& topic, const PointCloud2& msg)>;
+    using Clock = std::function<uint64_t()>;        // nanoseconds; stands in for ros::Time::now()
+
+    explicit CloudMergerNode(const NodeConfig& cfg);
+    ~CloudMergerNode();
+    CloudMergerNode(const CloudMergerNode&) = delete;
+    CloudMergerNode& operator=(const CloudMergerNode&) = delete;
+
+    bool ok() const { return ctx_ != nullptr; }
+    const std::string& error() const { return error_; }
+    const NodeConfig& config() const { return cfg_; }
+    int sensor_by_topic(const std::string& topic) const;
+
+    // Result of listener.lookupTransform(base_frame, sensor.frame, Time(0)) (:556-561): the
+    // quaternion/origin tf::Transform hands pcl_ros (:320).
+    int set_transform(size_t sensor, const double q_xyzw[4], const double t_xyz[3]);
+    bool transforms_ready() const;                  // flag_tf (:551,:562)
+
+    // Subscriber callback body (:318-337 and siblings). Callable concurrently for different
+    // sensors (AsyncSpinner(6), :513). Returns a cm_status; clouds are ignored until every
+    // transform is known, like the reference, whose callbacks run on default transforms before
+    // flag_tf but whose fuse gate only opens afterwards.
+    int on_cloud(size_t sensor, const PointCloud2& msg);
+
+    void set_publisher(Publisher p) { publish_ = std::move(p); }
+    void set_clock(Clock c) { clock_ = std::move(c); }
+
+    // One pass of the main loop body (:570-580): fuse when the required sensors are fresh,
+    // voxelise, publish. Returns CM_OK (published), CM_NOT_READY (tick skipped, :575) or an error.
+    int spin_once(cm_result* res = nullptr);
+    // while(ros::ok()) { spin_once(); loop_rate.sleep(); } (:549-584)
+    void run(const std::atomic<bool>& stop);
+
+    uint64_t frames_published() const { return frames_; }
+
+private:
+    NodeConfig cfg_;
+    cm_ctx* ctx_ = nullptr;
+    std::vector<std::atomic<bool>> have_tf_;
+    Publisher publish_;
+    Clock clock_;
+    std::string error_;
+    std::atomic<uint64_t> frames_{0};
+    uint32_t seq_ = 0;
+};
+
+}  // namespace cloudmerge

@@ -1,0 +1,16 @@
+// pcd_io.hpp — PCD v0.7 reader/writer for the replay driver (the reference replays rosbags it does
+// not ship: my_cloud_fusion/launch/bag.launch:7; recorded frames here are .pcd files).
+// Supports FLOAT32 fields, DATA ascii and DATA binary (not binary_compressed).
+#pragma once
+#include <string>
+
+#include "pointcloud2.hpp"
+
+namespace cloudmerge {
+
+// Returns false and fills *err on failure.
+bool read_pcd(const std::string& path, PointCloud2* out, std::string* err);
+// Writes every field of msg (all must be FLOAT32 count 1) as DATA binary.
+bool write_pcd(const std::string& path, const PointCloud2& msg, std::string* err);
+
+}  // namespace cloudmerge

@@ -1,0 +1,126 @@
+// replay_main.cpp — replays a recorded multi-sensor .pcd sequence through CloudMergerNode, the way
+// the reference is exercised with `rosbag play` (my_cloud_fusion/launch/bag.launch:7). BASELINE
+// config 4: frames are independent, so `--shard r/w` gives rank r every w-th frame (one process
+// per GPU, no collective).
+//
+//   cloudmerge_replay --dir SEQ --sensors 4 --frames 100 [--leaf 0.05] [--min-pts 2]
+//                     [--crop x0 y0 z0 x1 y1 z1] [--out OUTDIR] [--device 0] [--shard 0/1]
+//                     [--rate 10 --realtime]
+// SEQ/transforms.txt : one line per sensor "qx qy qz qw tx ty tz" (tf lookup results)
+// SEQ/frame_%04d_sensor_%d.pcd : FIELDS x y z [intensity], FLOAT32
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "merger_node.hpp"
+#include "pcd_io.hpp"
+
+using namespace cloudmerge;
+
+int main(int argc, char** argv) {
+    std::string dir, out_dir;
+    int n_sensors = 4, n_frames = 1, device = 0, rank = 0, world = 1;
+    double rate = 10.0;
+    bool realtime = false;
+    NodeConfig cfg;
+    cfg.params.leaf[0] = cfg.params.leaf[1] = cfg.params.leaf[2] = 0.05f;
+    cfg.params.min_points_per_voxel = 2;
+    cfg.params.downsample_all_data = 1;
+    for (int a = 1; a < argc; ++a) {
+        const std::string k = argv[a];
+        auto next = [&](int n = 1) { if (a + n >= argc) { std::fprintf(stderr, "missing value for %s\n", k.c_str()); std::exit(2); } return argv[++a]; };
+        if (k == "--dir") dir = next();
+        else if (k == "--out") out_dir = next();
+        else if (k == "--sensors") n_sensors = std::atoi(next());
+        else if (k == "--frames") n_frames = std::atoi(next());
+        else if (k == "--device") device = std::atoi(next());
+        else if (k == "--rate") rate = std::atof(next());
+        else if (k == "--realtime") realtime = true;
+        else if (k == "--leaf") { const float v = std::strtof(next(), nullptr); cfg.params.leaf[0] = cfg.params.leaf[1] = cfg.params.leaf[2] = v; }
+        else if (k == "--min-pts") cfg.params.min_points_per_voxel = static_cast<uint32_t>(std::atoi(next()));
+        else if (k == "--crop") {
+            cfg.params.crop_enable = 1;
+            for (int i = 0; i < 3; ++i) cfg.params.crop_min[i] = std::strtof(next(), nullptr);
+            for (int i = 0; i < 3; ++i) cfg.params.crop_max[i] = std::strtof(next(), nullptr);
+        } else if (k == "--shard") {
+            if (std::sscanf(next(), "%d/%d", &rank, &world) != 2 || world < 1 || rank < 0 || rank >= world) { std::fprintf(stderr, "bad --shard\n"); return 2; }
+        } else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
+    }
+    if (dir.empty() || n_sensors < 1 || n_sensors > CM_MAX_SENSORS) { std::fprintf(stderr, "usage: see header of replay_main.cpp\n"); return 2; }
+
+    for (int s = 0; s < n_sensors; ++s)
+        cfg.sensors.push_back({"sensor" + std::to_string(s), "/sensor" + std::to_string(s) + "/points", "/sensor" + std::to_string(s), true});
+    cfg.device = device;
+    cfg.rate_hz = rate;
+    cfg.max_points_total = 0;
+
+    // size the context from the first frame
+    std::string err;
+    std::vector<PointCloud2> clouds(n_sensors);
+    auto frame_path = [&](int f, int s) {
+        char buf[64];
+        std::snprintf(buf, sizeof buf, "/frame_%04d_sensor_%d.pcd", f, s);
+        return dir + buf;
+    };
+    size_t first_total = 0;
+    for (int s = 0; s < n_sensors; ++s) {
+        if (!read_pcd(frame_path(rank, s), &clouds[s], &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        first_total += clouds[s].num_points();
+    }
+    cfg.max_points_total = first_total + first_total / 2 + 1024;
+
+    CloudMergerNode node(cfg);
+    if (!node.ok()) { std::fprintf(stderr, "node: %s\n", node.error().c_str()); return 1; }
+    {
+        std::ifstream tf(dir + "/transforms.txt");
+        for (int s = 0; s < n_sensors; ++s) {
+            double q[4] = {0, 0, 0, 1}, t[3] = {0, 0, 0};
+            if (tf) tf >> q[0] >> q[1] >> q[2] >> q[3] >> t[0] >> t[1] >> t[2];
+            node.set_transform(static_cast<size_t>(s), q, t);
+        }
+    }
+    uint64_t voxels = 0, points = 0;
+    int cur_frame = 0;
+    node.set_publisher([&](const std::string&, const PointCloud2& msg) {
+        voxels += msg.num_points();
+        if (!out_dir.empty()) {
+            char buf[64];
+            std::snprintf(buf, sizeof buf, "/voxel_%04d.pcd", cur_frame);
+            std::string e;
+            if (!write_pcd(out_dir + buf, msg, &e)) std::fprintf(stderr, "%s\n", e.c_str());
+        }
+    });
+
+    const auto t0 = std::chrono::steady_clock::now();
+    double t_gpu = 0;
+    int done = 0;
+    for (int f = rank; f < n_frames; f += world) {
+        cur_frame = f;
+        for (int s = 0; s < n_sensors; ++s) {
+            if (f != rank || clouds[s].data.empty())
+                if (!read_pcd(frame_path(f, s), &clouds[s], &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
+            points += clouds[s].num_points();
+        }
+        const auto g0 = std::chrono::steady_clock::now();
+        for (int s = 0; s < n_sensors; ++s) {
+            const int st = node.on_cloud(static_cast<size_t>(s), clouds[s]);
+            if (st != CM_OK) { std::fprintf(stderr, "on_cloud: %s (%s)\n", cm_status_string(st), node.error().c_str()); return 1; }
+        }
+        cm_result r{};
+        const int st = node.spin_once(&r);
+        t_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - g0).count();
+        if (st < 0 || st == CM_NOT_READY) { std::fprintf(stderr, "frame %d: %s\n", f, cm_status_string(st)); return 1; }
+        ++done;
+        if (realtime) std::this_thread::sleep_until(t0 + std::chrono::duration<double>(done / rate));
+    }
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("{\"rank\": %d, \"world\": %d, \"frames\": %d, \"points_in\": %llu, \"voxels_out\": %llu, "
+                "\"wall_s\": %.6f, \"submit_merge_publish_s\": %.6f, \"frames_per_s\": %.2f, \"points_per_s\": %.3e}\n",
+                rank, world, done, static_cast<unsigned long long>(points), static_cast<unsigned long long>(voxels), wall,
+                t_gpu, done / t_gpu, points / t_gpu);
+    return 0;
+}
