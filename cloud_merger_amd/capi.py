@@ -29,7 +29,13 @@ SYMBOLS = [
     "cm_merge_voxelize", "cm_merge_voxelize_async", "cm_wait", "cm_result_copy", "cm_result_device",
     "cm_result_copy_cells", "cm_merged_copy", "cm_get_stage_times", "cm_status_string",
     "cm_last_error", "cm_version", "cm_host_alloc", "cm_host_free",
+    "cm_local_bounds", "cm_merge_partial", "cm_partial_device", "cm_partial_copy", "cm_merge_tables",
 ]
+
+# cm_partial_entry (32 bytes)
+ENTRY_DTYPE = np.dtype([("key", "<u4"), ("count", "<u4"), ("sx", "<f4"), ("sy", "<f4"), ("sz", "<f4"),
+                        ("si", "<f4"), ("_pad", "<u4", (2,))])
+assert ENTRY_DTYPE.itemsize == 32
 
 
 class Limits(C.Structure):
@@ -67,7 +73,11 @@ _lib = None
 
 
 def load():
-    """Load the in-tree HIP library; raises if it has not been built."""
+    """Load the in-tree HIP library; raises if it has not been built.
+
+    A process that also uses PyTorch must `import torch` BEFORE this is called: torch bundles its
+    own libamdhip64/libhsa-runtime64, and the first HIP runtime loaded serves the whole process
+    (same soname). Loaded the other way round torch finds no GPU."""
     global _lib
     if _lib is not None:
         return _lib
@@ -98,6 +108,11 @@ def load():
     L.cm_last_error.argtypes = [vp]
     L.cm_last_error.restype = C.c_char_p
     L.cm_version.argtypes = []
+    L.cm_local_bounds.argtypes = [vp, C.POINTER(Params), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(u64)]
+    L.cm_merge_partial.argtypes = [vp, C.POINTER(Params), C.POINTER(C.c_float), C.POINTER(Result)]
+    L.cm_partial_device.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    L.cm_partial_copy.argtypes = [vp, vp, u64]
+    L.cm_merge_tables.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), u32, C.POINTER(Params), C.POINTER(Result)]
     L.cm_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
     L.cm_host_free.argtypes = [vp]
     for name in SYMBOLS:
@@ -239,6 +254,43 @@ class CloudMerger:
         n = C.c_uint64()
         self._check(self._lib.cm_merged_copy(self._ctx, out.ctypes.data, int(capacity), C.byref(n)), "cm_merged_copy")
         return out[: n.value].copy()
+
+    # ---- fused cloud across GPUs ----
+    def local_bounds(self, params: MergeParams):
+        mn, mx, n = (C.c_float * 3)(), (C.c_float * 3)(), C.c_uint64()
+        self._check(self._lib.cm_local_bounds(self._ctx, C.byref(make_params(params)), mn, mx, C.byref(n)),
+                    "cm_local_bounds")
+        return np.array(mn, dtype=np.float32), np.array(mx, dtype=np.float32), n.value
+
+    def merge_partial(self, params: MergeParams, global_min_max=None) -> Result:
+        res = Result()
+        b = None if global_min_max is None else (C.c_float * 6)(*[float(v) for v in global_min_max])
+        st = self._lib.cm_merge_partial(self._ctx, C.byref(make_params(params)), b, C.byref(res))
+        self._check(st, "cm_merge_partial", ok=(OK, EMPTY_INPUT, NOT_READY))
+        return res
+
+    def partial_device(self):
+        ptr, n = C.c_void_p(), C.c_uint64()
+        self._check(self._lib.cm_partial_device(self._ctx, C.byref(ptr), C.byref(n)), "cm_partial_device")
+        return ptr.value, n.value
+
+    def partial(self, n_entries):
+        out = np.zeros(int(n_entries), dtype=ENTRY_DTYPE)
+        self._check(self._lib.cm_partial_copy(self._ctx, out.ctypes.data if n_entries else None, int(n_entries)),
+                    "cm_partial_copy")
+        return out
+
+    def partial_to_device(self, dst_ptr, capacity):
+        self._check(self._lib.cm_partial_copy(self._ctx, C.c_void_p(dst_ptr), int(capacity)), "cm_partial_copy")
+
+    def merge_tables(self, table_ptrs, counts, params: MergeParams) -> Result:
+        n = len(table_ptrs)
+        ptrs = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in table_ptrs])
+        cnts = (C.c_uint64 * n)(*[int(v) for v in counts])
+        res = Result()
+        st = self._lib.cm_merge_tables(self._ctx, ptrs, cnts, n, C.byref(make_params(params)), C.byref(res))
+        self._check(st, "cm_merge_tables", ok=(OK, EMPTY_INPUT))
+        return res
 
     def stage_times(self):
         t = StageTimes()

@@ -18,6 +18,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
+#include <algorithm>
 #include <mutex>
 #include <new>
 #include <string>
@@ -58,6 +60,9 @@ struct cm_ctx {
     uint32_t *out_key = nullptr, *out_cnt = nullptr, *merged_total = nullptr;
     void* out = nullptr;
     void* merged = nullptr;
+    void* partial = nullptr;             // cm_partial_entry table of the last cm_merge_partial
+    void* table_entries = nullptr;       // merged entries inside cm_merge_tables
+    int last_mode = 0;
     CmFrameDev* d_frame = nullptr;
     CmFrameDev frame_uploaded;
     bool frame_uploaded_valid = false;
@@ -132,18 +137,18 @@ void quat_to_rows(const double q[4], const double t[3], float m[12]) {
     m[8] = txz - twy;          m[9] = tyz + twx;          m[10] = 1.0f - (txx + tyy); m[11] = static_cast<float>(t[2]);
 }
 
-// Host copy of k_bounds' guard for the crop box: true when the box itself fits PCL's int32 index,
+// Host copy of the kernels' grid guard for a box (the crop box, or bounds handed in): true when the box itself fits PCL's int32 index,
 // in which case the data min/max pass can be skipped (box-relative indices give the same
 // occupancy and the same order). Also returns the key width.
-bool crop_box_grid(const cm_params& p, const float inv[3], uint32_t* key_bits) {
+bool box_grid(const float bmin[3], const float bmax[3], const float inv[3], uint32_t* key_bits) {
     long long d[3];
     unsigned long long cells = 1;
     for (int a = 0; a < 3; ++a) {
-        const float ext = (p.crop_max[a] - p.crop_min[a]) * inv[a];
+        const float ext = (bmax[a] - bmin[a]) * inv[a];
         if (!(ext < 2147483648.0f) || ext < 0.0f) return false;
         d[a] = static_cast<long long>(ext) + 1;
-        const int lo = static_cast<int>(std::floor(p.crop_min[a] * inv[a]));
-        const int hi = static_cast<int>(std::floor(p.crop_max[a] * inv[a]));
+        const int lo = static_cast<int>(std::floor(bmin[a] * inv[a]));
+        const int hi = static_cast<int>(std::floor(bmax[a] * inv[a]));
         if (hi < lo) return false;
         cells *= static_cast<unsigned long long>(hi - lo + 1);
     }
@@ -170,7 +175,7 @@ void prof_mark(cm_ctx* c, const char* name) {
 void free_all(cm_ctx* c) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(c->keys_a); F(c->keys_b); F(c->vals_a); F(c->vals_b); F(c->hist); F(c->totals);
-    F(c->seg_counts); F(c->seg_tile_counts); F(c->seg_groups); F(c->grp); F(c->partials); F(c->out_key); F(c->out_cnt); F(c->merged_total); F(c->out); F(c->merged);
+    F(c->seg_counts); F(c->seg_tile_counts); F(c->seg_groups); F(c->grp); F(c->partials); F(c->out_key); F(c->out_cnt); F(c->merged_total); F(c->out); F(c->merged); F(c->partial); F(c->table_entries);
     F(c->d_frame); F(c->d_state[0]); F(c->d_state[1]);
     if (c->h_state) (void)hipHostFree(c->h_state);
     for (auto& s : c->slots) {
@@ -220,14 +225,7 @@ int set_slot_cloud(cm_ctx* c, uint32_t sensor, const void* data, bool on_device,
 }
 
 // Builds the frame descriptor and enqueues every kernel of the frame on c->stream.
-int enqueue(cm_ctx* c, const cm_params* p) {
-    if (!c || !p) return CM_BAD_ARG;
-    for (int a = 0; a < 3; ++a)
-        if (!(p->leaf[a] > 0.0f) || !std::isfinite(p->leaf[a])) return fail(c, CM_BAD_ARG, "leaf must be > 0");
-    HIP_TRY(c, hipSetDevice(c->device));
-    if (c->pending) return fail(c, CM_BAD_ARG, "previous frame not waited for (cm_wait)");
-
-    std::vector<std::unique_lock<std::mutex>> locks;
+int build_frame(cm_ctx* c, const cm_params* p, bool consume, std::vector<std::unique_lock<std::mutex>>& locks) {
     for (uint32_t s = 0; s < c->max_sensors; ++s) locks.emplace_back(c->slots[s].mu);
 
     // Frame assembly policy (pc_preprocessing_main.cpp:134-157).
@@ -273,11 +271,32 @@ int enqueue(cm_ctx* c, const cm_params* p) {
     f.downsample_all = p->downsample_all_data ? 1u : 0u;
     c->n_in = n_in;
     c->n_sensors_used = k;
+    if (consume)
+        for (auto& sl : c->slots) sl.fresh = false;   // flag reset, :151-157
+    return CM_OK;
+}
+
+// mode 0: the path (centroids). mode 1: partial table of per-voxel sums (fused cloud across GPUs);
+// `bounds` (min xyz, max xyz of the whole fused cloud) then fixes the grid unless the crop box does.
+// consume: reset the "fresh" flags (a frame was fused); false for cm_local_bounds' peek.
+int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = nullptr) {
+    if (!c || !p) return CM_BAD_ARG;
+    for (int a = 0; a < 3; ++a)
+        if (!(p->leaf[a] > 0.0f) || !std::isfinite(p->leaf[a])) return fail(c, CM_BAD_ARG, "leaf must be > 0");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->pending) return fail(c, CM_BAD_ARG, "previous frame not waited for (cm_wait)");
+
+    std::vector<std::unique_lock<std::mutex>> locks;
+    const int bf = build_frame(c, p, true, locks);
+    if (bf != CM_OK) return bf;
+    CmFrameDev& f = c->frame;
+    if (mode == 1 && bounds) {
+        for (int a = 0; a < 3; ++a) { f.ext_min[a] = bounds[a]; f.ext_max[a] = bounds[3 + a]; }
+    }
     c->have_result = false;
     c->out_is_merged = false;
     c->prof_used = 0;
-
-    for (auto& sl : c->slots) sl.fresh = false;       // flag reset, :151-157
+    c->last_mode = mode;
 
     if (f.n_padded == 0) {                             // every submitted cloud is empty
         c->pending = true;
@@ -295,7 +314,11 @@ int enqueue(cm_ctx* c, const cm_params* p) {
     CmFrameState* state = c->d_state[c->cur];
     CmFrameState* state_next = c->d_state[c->cur ^ 1];
     uint32_t key_bits = 0;
-    c->from_crop = f.crop_enable && crop_box_grid(*p, f.inv_leaf, &key_bits);
+    int grid_mode = 0;                               // 0: data min/max (k_minmax), 1: crop box, 2: bounds handed in
+    if (f.crop_enable && box_grid(p->crop_min, p->crop_max, f.inv_leaf, &key_bits)) grid_mode = 1;
+    else if (mode == 1 && bounds && box_grid(bounds, bounds + 3, f.inv_leaf, &key_bits)) grid_mode = 2;
+    else if (mode == 1) return fail(c, CM_BAD_ARG, "partial table needs the crop box or the fused cloud's bounds to fix the grid");
+    c->from_crop = grid_mode != 0;
     const uint32_t passes = c->from_crop ? (key_bits + CM_RADIX_BITS - 1) / CM_RADIX_BITS : CM_MAX_PASSES;
     const uint32_t nt = f.n_tiles;
     const uint32_t nseg = f.n_padded / CM_SEG_TILE;
@@ -314,7 +337,7 @@ int enqueue(cm_ctx* c, const cm_params* p) {
     prof_mark(c, "k_keys");
     cmk_keys(st, c->d_frame, state, c->keys_a, c->hist, grp0, grp0_next, c->grp + 2 * gstride, gw,
              static_cast<uint32_t>(gstride), c->seg_groups, (nseg + CM_SEG_GROUP - 1) / CM_SEG_GROUP + 1,
-             c->partials, n_partials, c->from_crop ? 1 : 0, nt);
+             c->partials, n_partials, grid_mode, nt);
     // NOTE: k_keys clears 3*gw words starting at grp[2]; passes 1..3 therefore live at stride gw.
     for (uint32_t pass = 0; pass < passes; ++pass) {
         const bool even = (pass & 1u) == 0;
@@ -331,10 +354,13 @@ int enqueue(cm_ctx* c, const cm_params* p) {
     }
     prof_mark(c, "k_seg_count");
     uint32_t* seg_groups = nseg > CM_SEG_DIRECT_TILES ? c->seg_groups : nullptr;
-    cmk_seg_count(st, state, c->keys_a, c->keys_b, c->seg_tile_counts, seg_groups, f.min_pts, nseg);
+    cmk_seg_count(st, state, c->keys_a, c->keys_b, c->seg_tile_counts, seg_groups, mode == 1 ? 1u : f.min_pts, nseg);
     prof_mark(c, "k_seg_reduce");
-    cmk_seg_reduce(st, c->d_frame, state, state_next, c->h_state_dev, c->keys_a, c->vals_a, c->keys_b,
-                   c->vals_b, c->seg_tile_counts, seg_groups, c->out, c->out_key, c->out_cnt, nseg);
+    if (mode == 1 && !c->partial)
+        HIP_TRY(c, hipMalloc(&c->partial, static_cast<size_t>(c->cap_padded) * 32));
+    cmk_seg_reduce(st, mode, c->d_frame, state, state_next, c->h_state_dev, c->keys_a, c->vals_a, c->keys_b,
+                   c->vals_b, c->seg_tile_counts, seg_groups, mode == 1 ? c->partial : c->out, c->out_key,
+                   c->out_cnt, nseg);
     prof_mark(c, "end");
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_done, st));     // k_seg_reduce wrote the state record to h_state
@@ -672,6 +698,184 @@ int cm_merged_copy(cm_ctx* c, void* host_dst, uint64_t capacity, uint64_t* n_poi
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     return CM_OK;
+}
+
+int cm_local_bounds(cm_ctx* c, const cm_params* p, float min_xyz[3], float max_xyz[3], uint64_t* n_valid) {
+    if (!c || !p || !min_xyz || !max_xyz) return CM_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->merge_mu);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->pending) return fail(c, CM_BAD_ARG, "previous frame not waited for (cm_wait)");
+    for (int a = 0; a < 3; ++a)
+        if (!(p->leaf[a] > 0.0f)) return fail(c, CM_BAD_ARG, "leaf must be > 0");
+    std::vector<std::unique_lock<std::mutex>> locks;
+    const int bf = build_frame(c, p, false, locks);          // a peek: the clouds stay fresh
+    if (bf != CM_OK) return bf;
+    const float inf = std::numeric_limits<float>::infinity();
+    for (int a = 0; a < 3; ++a) { min_xyz[a] = inf; max_xyz[a] = -inf; }
+    if (n_valid) *n_valid = 0;
+    const CmFrameDev& f = c->frame;
+    if (f.n_padded == 0) return CM_OK;
+    cmk_setup(c->stream, f, c->d_frame);
+    c->frame_uploaded = f;
+    c->frame_uploaded_valid = true;
+    const uint32_t n_partials = f.n_tiles < CM_MINMAX_BLOCKS ? f.n_tiles : CM_MINMAX_BLOCKS;
+    cmk_minmax(c->stream, c->d_frame, c->partials, n_partials);
+    std::vector<float> rec(static_cast<size_t>(n_partials) * 8);
+    HIP_TRY(c, hipMemcpyAsync(rec.data(), c->partials, rec.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint64_t cnt = 0;
+    for (uint32_t r = 0; r < n_partials; ++r) {
+        uint32_t k;
+        std::memcpy(&k, &rec[r * 8 + 6], 4);
+        if (!k) continue;
+        cnt += k;
+        for (int a = 0; a < 3; ++a) {
+            min_xyz[a] = std::min(min_xyz[a], rec[r * 8 + a]);
+            max_xyz[a] = std::max(max_xyz[a], rec[r * 8 + 3 + a]);
+        }
+    }
+    if (n_valid) *n_valid = cnt;
+    return CM_OK;
+}
+
+int cm_merge_partial(cm_ctx* c, const cm_params* p, const float* global_min_max, cm_result* res) {
+    if (!c) return CM_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->merge_mu);
+    const int e = enqueue(c, p, 1, global_min_max);
+    if (e != CM_OK) {
+        if (res) { std::memset(res, 0, sizeof *res); res->status = e; }
+        return e;
+    }
+    return wait_frame(c, res);
+}
+
+int cm_partial_device(cm_ctx* c, const void** dev_entries, uint64_t* n_entries) {
+    if (!c || !dev_entries || !n_entries) return CM_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->merge_mu);
+    if (!c->have_result || c->last_mode != 1) return fail(c, CM_BAD_ARG, "no partial table (cm_merge_partial)");
+    *dev_entries = c->partial;
+    *n_entries = c->result.status == CM_OK ? c->result.n_out : 0;
+    return CM_OK;
+}
+
+int cm_partial_copy(cm_ctx* c, cm_partial_entry* host_dst, uint64_t capacity) {
+    if (!c) return CM_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->merge_mu);
+    if (!c->have_result || c->last_mode != 1) return fail(c, CM_BAD_ARG, "no partial table (cm_merge_partial)");
+    const uint64_t n = c->result.status == CM_OK ? c->result.n_out : 0;
+    if (n > capacity) return fail(c, CM_CAPACITY, "destination too small");
+    if (n == 0) return CM_OK;
+    if (!host_dst) return CM_BAD_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(host_dst, c->partial, n * 32, hipMemcpyDefault, c->stream));   // host or device destination
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CM_OK;
+}
+
+int cm_merge_tables(cm_ctx* c, const void* const* dev_tables, const uint64_t* n_entries, uint32_t n_tables,
+                    const cm_params* p, cm_result* res) {
+    if (!c || !p || !dev_tables || !n_entries || n_tables < 1 || n_tables > CM_MAX_SENSORS) return CM_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->merge_mu);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->pending) return fail(c, CM_BAD_ARG, "previous frame not waited for (cm_wait)");
+    // The tables take the place of the sensor clouds: table t owns a tile-aligned range of the
+    // padded index space, so the point index a key carries maps back to (table, entry).
+    CmFrameDev& f = c->frame;
+    std::memset(&f, 0, sizeof f);
+    uint32_t base = 0;
+    uint64_t total = 0;
+    for (uint32_t t = 0; t < n_tables; ++t) {
+        if (n_entries[t] && (!dev_tables[t] || (reinterpret_cast<uintptr_t>(dev_tables[t]) & 15u)))
+            return fail(c, CM_BAD_ARG, "table pointers must be 16-byte aligned device memory");
+        CmSensorDev& d = f.s[t];
+        d.data = static_cast<const unsigned char*>(dev_tables[t]);
+        d.n = static_cast<uint32_t>(n_entries[t]);
+        d.base = base;
+        d.point_step = 32;
+        const uint64_t nb = static_cast<uint64_t>(base) + round_up(d.n, CM_TILE);
+        if (nb > c->cap_padded) return fail(c, CM_CAPACITY, "tables exceed cm_limits.max_points_total");
+        base = static_cast<uint32_t>(nb);
+        total += n_entries[t];
+    }
+    f.n_sensors = n_tables;
+    f.n_padded = base;
+    f.n_tiles = base / CM_TILE;
+    f.min_pts = p->min_points_per_voxel;
+    f.downsample_all = 1;
+    cm_result r;
+    std::memset(&r, 0, sizeof r);
+    if (c->have_result && c->last_mode == 1) {       // keep the shared grid of this rank's partial table
+        for (int a = 0; a < 3; ++a) {
+            r.min_b[a] = c->result.min_b[a]; r.max_b[a] = c->result.max_b[a]; r.div_b[a] = c->result.div_b[a];
+            r.min_p[a] = c->result.min_p[a]; r.max_p[a] = c->result.max_p[a];
+        }
+        r.bounds_from_crop = c->result.bounds_from_crop;
+    }
+    r.n_sensors = n_tables;
+    r.n_in = total;
+    c->have_result = false;
+    c->last_mode = 2;
+    c->prof_used = 0;
+    if (f.n_padded == 0) {
+        r.status = CM_EMPTY_INPUT;
+        c->result = r; c->have_result = true;
+        if (res) *res = r;
+        return r.status;
+    }
+    hipStream_t st = c->stream;
+    cmk_setup(st, f, c->d_frame);
+    c->frame_uploaded = f;
+    c->frame_uploaded_valid = true;
+    CmFrameState* state = c->d_state[c->cur];
+    CmFrameState* state_next = c->d_state[c->cur ^ 1];
+    const uint32_t nt = f.n_tiles, nseg = f.n_padded / CM_SEG_TILE;
+    const uint32_t n_groups = (nt + CM_GROUP - 1) / CM_GROUP, gw = n_groups * CM_RADIX;
+    const size_t gstride = static_cast<size_t>(c->cap_groups) * CM_RADIX;
+    uint32_t* grp0 = c->grp + gstride * (c->frame_seq & 1u);
+    uint32_t* grp0_next = c->grp + gstride * ((c->frame_seq & 1u) ^ 1u);
+    ++c->frame_seq;
+    const bool big = n_groups > CM_DIRECT_GROUPS;
+    if (!c->table_entries) HIP_TRY(c, hipMalloc(&c->table_entries, static_cast<size_t>(c->cap_padded) * 32));
+    cmk_table_keys(st, c->d_frame, state, c->keys_a, c->hist, grp0, grp0_next, c->grp + 2 * gstride, gw,
+                   static_cast<uint32_t>(gstride), c->seg_groups, (nseg + CM_SEG_GROUP - 1) / CM_SEG_GROUP + 1, 32u, nt);
+    for (uint32_t pass = 0; pass < CM_MAX_PASSES; ++pass) {
+        const bool even = (pass & 1u) == 0;
+        const uint32_t* kin = even ? c->keys_a : c->keys_b;
+        const uint32_t* vin = even ? c->vals_a : c->vals_b;
+        uint32_t* kout = even ? c->keys_b : c->keys_a;
+        uint32_t* vout = even ? c->vals_b : c->vals_a;
+        uint32_t* grp = pass == 0 ? grp0 : c->grp + 2 * gstride + static_cast<size_t>(pass - 1) * gw;
+        if (pass > 0) cmk_hist(st, state, kin, c->hist, grp, pass, nt);
+        if (big) cmk_gscan(st, state, grp, c->totals, pass, n_groups);
+        cmk_scatter(st, state, kin, vin, kout, vout, c->hist, grp, big ? c->totals : nullptr, pass, nt, n_groups,
+                    f.n_padded, c->lds_rank);
+    }
+    uint32_t* seg_groups = nseg > CM_SEG_DIRECT_TILES ? c->seg_groups : nullptr;
+    cmk_seg_count(st, state, c->keys_a, c->keys_b, c->seg_tile_counts, seg_groups, 1u, nseg);
+    cmk_seg_reduce(st, 2, c->d_frame, state, state_next, c->h_state_dev, c->keys_a, c->vals_a, c->keys_b, c->vals_b,
+                   c->seg_tile_counts, seg_groups, c->table_entries, nullptr, nullptr, nseg);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(st));
+    c->cur ^= 1;
+    const CmFrameState& h = *c->h_state;
+    const uint32_t n_merged = h.status == CM_OK ? h.n_out : 0;       // distinct voxels over all tables
+    uint32_t n_out = 0;
+    if (n_merged) {
+        cmk_table_finish(st, c->table_entries, n_merged, p->min_points_per_voxel, c->seg_counts, c->merged_total,
+                         c->out, c->out_key, c->out_cnt);
+        HIP_TRY(c, hipMemcpyAsync(&n_out, c->merged_total, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+    }
+    r.status = n_merged ? CM_OK : CM_EMPTY_INPUT;
+    r.n_merged = n_merged;
+    r.n_out = n_out;
+    r.key_bits = 32; r.sort_passes = CM_MAX_PASSES;
+    r.path_flags = c->lds_rank ? 1u : 0u;
+    c->result = r;
+    c->have_result = true;
+    c->out_is_merged = false;
+    if (res) *res = r;
+    return r.status;
 }
 
 int cm_get_stage_times(cm_ctx* c, cm_stage_times* out) {

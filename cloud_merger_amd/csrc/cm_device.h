@@ -51,6 +51,8 @@ struct CmFrameDev {
     float inv_leaf[3];        // 1.0f / leaf, computed once on the host in fp32
     uint32_t min_pts;
     uint32_t downsample_all;
+    float ext_min[3];         // grid bounds handed in by the host (fused cloud across GPUs: the
+    float ext_max[3];         // min/max of the WHOLE merged cloud, all-reduced over the ranks)
 };
 
 // Per-frame device state, zeroed before the first kernel of a frame.

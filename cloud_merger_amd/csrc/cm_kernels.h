@@ -22,10 +22,17 @@ void cmk_scatter(hipStream_t s, CmFrameState* st, const uint32_t* keys_in, const
 void cmk_probe_lds_order(hipStream_t s, uint32_t* violations, uint32_t rounds);
 void cmk_seg_count(hipStream_t s, const CmFrameState* st, const uint32_t* keys_a, const uint32_t* keys_b,
                    uint32_t* counts, uint32_t* group_counts, uint32_t min_pts, uint32_t n_seg_tiles);
-void cmk_seg_reduce(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next,
+// mode: 0 points -> centroids, 1 points -> partial entries, 2 partial entries -> merged entries
+void cmk_seg_reduce(hipStream_t s, int mode, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next,
                     uint32_t* host_state, const uint32_t* keys_a, const uint32_t* vals_a,
                     const uint32_t* keys_b, const uint32_t* vals_b, const uint32_t* counts,
                     const uint32_t* group_counts, void* out, uint32_t* out_key, uint32_t* out_cnt,
                     uint32_t n_seg_tiles);
+void cmk_table_keys(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* keys, uint32_t* hist,
+                    uint32_t* grp_acc, uint32_t* grp_clear_a, uint32_t* grp_clear_b, uint32_t n_group_words,
+                    uint32_t n_clear_a_words, uint32_t* seg_groups, uint32_t n_seg_groups, uint32_t key_bits,
+                    uint32_t n_tiles);
+void cmk_table_finish(hipStream_t s, const void* entries, uint32_t n, uint32_t min_pts, uint32_t* tile_counts,
+                      uint32_t* total, void* out, uint32_t* out_key, uint32_t* out_cnt);
 void cmk_merged(hipStream_t s, const CmFrameDev* fd, uint32_t* tile_counts, uint32_t* total, void* out,
                 uint32_t n_tiles);

@@ -239,7 +239,10 @@ __device__ __forceinline__ void compute_grid(const CmFrameDev* __restrict__ fd,
     g.key_bits = 0; g.n_passes = 0; g.n_valid_k0 = 0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) { g.min_b[a] = 0; g.max_b[a] = 0; g.div_b[a] = 1; g.min_p[a] = 0.f; g.max_p[a] = 0.f; }
-    if (from_crop) {
+    if (from_crop == 2) {                               // bounds of the whole fused cloud, from the host
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { g.min_p[a] = fd->ext_min[a]; g.max_p[a] = fd->ext_max[a]; }
+    } else if (from_crop) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) { g.min_p[a] = fd->crop_min[a]; g.max_p[a] = fd->crop_max[a]; }
     } else {
@@ -714,16 +717,31 @@ struct SensorLds {
     float m[12];
 };
 
-__device__ __forceinline__ Pt gather_point(const SensorLds* __restrict__ tab, uint32_t n_sensors, uint32_t gidx) {
+// What the centroid kernel sums. SEG_CENTROIDS: points -> voxel means (the path). SEG_PARTIAL:
+// points -> per-voxel sums and counts, no threshold (one GPU's share of a fused cloud).
+// SEG_TABLES: 32-byte partial entries of several GPUs -> merged sums and counts.
+enum { SEG_CENTROIDS = 0, SEG_PARTIAL = 1, SEG_TABLES = 2 };
+
+template <int MODE>
+__device__ __forceinline__ Acc gather_item(const SensorLds* __restrict__ tab, uint32_t n_sensors, uint32_t gidx,
+                                           bool all_fields) {
     uint32_t s = 0;
     for (uint32_t q = 1; q < n_sensors; ++q) s += (gidx >= tab[q].base) ? 1u : 0u;
     const SensorLds& sd = tab[s];
-    const Pt p = load_point(sd.data, sd.layout, sd.step, sd.ox, sd.oy, sd.oz, sd.oi, gidx - sd.base);
-    Pt o;
-    o.x = xf_row(sd.m[0], sd.m[1], sd.m[2], sd.m[3], p.x, p.y, p.z);
-    o.y = xf_row(sd.m[4], sd.m[5], sd.m[6], sd.m[7], p.x, p.y, p.z);
-    o.z = xf_row(sd.m[8], sd.m[9], sd.m[10], sd.m[11], p.x, p.y, p.z);
-    o.i = p.i;
+    Acc o;
+    if (MODE == SEG_TABLES) {
+        const float4* e = reinterpret_cast<const float4*>(sd.data + static_cast<size_t>(gidx - sd.base) * 32);
+        const float4 lo = e[0], hi = e[1];
+        o.c = __float_as_uint(lo.y);
+        o.x = lo.z; o.y = lo.w; o.z = hi.x; o.i = hi.y;
+    } else {
+        const Pt p = load_point(sd.data, sd.layout, sd.step, sd.ox, sd.oy, sd.oz, sd.oi, gidx - sd.base);
+        o.x = xf_row(sd.m[0], sd.m[1], sd.m[2], sd.m[3], p.x, p.y, p.z);
+        o.y = xf_row(sd.m[4], sd.m[5], sd.m[6], sd.m[7], p.x, p.y, p.z);
+        o.z = xf_row(sd.m[8], sd.m[9], sd.m[10], sd.m[11], p.x, p.y, p.z);
+        o.i = all_fields ? p.i : 0.f;
+        o.c = 1u;
+    }
     return o;
 }
 
@@ -739,6 +757,7 @@ __device__ __forceinline__ void report_state(uint32_t* __restrict__ host, const 
     }
 }
 
+template <int MODE>
 __global__ __launch_bounds__(CM_BLOCK) void k_seg_reduce(const CmFrameDev* __restrict__ fd,
                                                          CmFrameState* __restrict__ st,
                                                          CmFrameState* __restrict__ st_next,
@@ -785,7 +804,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_seg_reduce(const CmFrameDev* __res
     const uint32_t n_tiles = (n + CM_SEG_TILE - 1) / CM_SEG_TILE;
     const uint32_t* __restrict__ keys = pick(st, keys_a, keys_b);
     const uint32_t* __restrict__ vals = pick(st, vals_a, vals_b);
-    const uint32_t min_pts = fd->min_pts > 1 ? fd->min_pts : 1u;
+    const uint32_t min_pts = (MODE == SEG_CENTROIDS && fd->min_pts > 1) ? fd->min_pts : 1u;
     const bool all_fields = fd->downsample_all != 0;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 
@@ -847,12 +866,11 @@ __global__ __launch_bounds__(CM_BLOCK) void k_seg_reduce(const CmFrameDev* __res
     }
 
     // gather + transform (only points whose run can survive the threshold)
-    Pt p[CM_SEG_ITEMS];
+    Acc it[CM_SEG_ITEMS];
 #pragma unroll
     for (int j = 0; j < CM_SEG_ITEMS; ++j) {
-        if (need >> j & 1u) p[j] = gather_point(tab, n_sensors, v[j]);
-        else { p[j].x = p[j].y = p[j].z = p[j].i = 0.f; }
-        if (!all_fields) p[j].i = 0.f;
+        if (need >> j & 1u) it[j] = gather_item<MODE>(tab, n_sensors, v[j], all_fields);
+        else { it[j].x = it[j].y = it[j].z = it[j].i = 0.f; it[j].c = 1u; }
     }
 
     // Extension: items after the tile that continue its last run (owned by this workgroup).
@@ -864,11 +882,8 @@ __global__ __launch_bounds__(CM_BLOCK) void k_seg_reduce(const CmFrameDev* __res
             const uint32_t kj = (off == 0) ? kext0 : ((j < n) ? keys[j] : 0u);
             const bool ok = (j < n) && (kj == klast);
             if (ok) {
-                Pt q = gather_point(tab, n_sensors, (off == 0) ? vext0 : vals[j]);
-                if (!all_fields) q.i = 0.f;
-                ext.x = __fadd_rn(ext.x, q.x); ext.y = __fadd_rn(ext.y, q.y);
-                ext.z = __fadd_rn(ext.z, q.z); ext.i = __fadd_rn(ext.i, q.i);
-                ext.c += 1;
+                const Acc q = gather_item<MODE>(tab, n_sensors, (off == 0) ? vext0 : vals[j], all_fields);
+                if (ext.c == 0) ext = q; else acc_add(ext, q);
             }
             any = any || ok;
             if (!__syncthreads_or(ok && threadIdx.x == CM_BLOCK - 1)) break;
@@ -907,16 +922,15 @@ __global__ __launch_bounds__(CM_BLOCK) void k_seg_reduce(const CmFrameDev* __res
     for (int j = 0; j < CM_SEG_ITEMS; ++j) {
         fin[j].x = fin[j].y = fin[j].z = fin[j].i = 0.f; fin[j].c = 0; fkey[j] = 0;
         if (live >> j & 1u) {
-            const Acc it = {p[j].x, p[j].y, p[j].z, p[j].i, 1u};
             if (heads >> j & 1u) {
                 if (open) { fin[j] = run; fkey[j] = run_key; fmask |= 1u << j; }
-                run = it; run_key = k[j]; open = true;
+                run = it[j]; run_key = k[j]; open = true;
             } else if (open) {
-                acc_add(run, it);
+                acc_add(run, it[j]);
             } else if (pre.c == 0) {
-                pre = it;
+                pre = it[j];
             } else {
-                acc_add(pre, it);
+                acc_add(pre, it[j]);
             }
         }
     }
@@ -985,15 +999,102 @@ __global__ __launch_bounds__(CM_BLOCK) void k_seg_reduce(const CmFrameDev* __res
         if (emit) {
             const Acc a = is_last ? run : fin[j & 7];
             const uint32_t ak = is_last ? run_key : fkey[j & 7];
-            const float c = static_cast<float>(a.c);
-            float4 o;
-            o.x = __fdiv_rn(a.x, c); o.y = __fdiv_rn(a.y, c);
-            o.z = __fdiv_rn(a.z, c); o.w = __fdiv_rn(a.i, c);
-            out[slot] = o;
-            if (out_key) { out_key[slot] = ak; out_cnt[slot] = a.c; }
+            if (MODE == SEG_CENTROIDS) {
+                const float c = static_cast<float>(a.c);
+                float4 o;
+                o.x = __fdiv_rn(a.x, c); o.y = __fdiv_rn(a.y, c);
+                o.z = __fdiv_rn(a.z, c); o.w = __fdiv_rn(a.i, c);
+                out[slot] = o;
+                if (out_key) { out_key[slot] = ak; out_cnt[slot] = a.c; }
+            } else {                                   // cm_partial_entry: key, count, sx, sy | sz, si, 0, 0
+                out[2 * static_cast<size_t>(slot)] = make_float4(__uint_as_float(ak), __uint_as_float(a.c), a.x, a.y);
+                out[2 * static_cast<size_t>(slot) + 1] = make_float4(a.z, a.i, 0.f, 0.f);
+            }
             ++slot;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused cloud across GPUs (nothing like it exists in the reference). Every GPU turns
+// its share of the sensors into a table of per-voxel sums (SEG_PARTIAL), the host all-gathers the
+// tables over RCCL, and the merge below re-sorts the concatenated entries by voxel index (stable:
+// equal voxels stay in rank order, so sums are deterministic), adds them (SEG_TABLES), and only
+// then applies min_points_per_voxel and divides — a voxel may hold one point on each of two GPUs.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(CM_BLOCK) void k_table_keys(const CmFrameDev* __restrict__ fd,
+                                                         CmFrameState* __restrict__ st,
+                                                         uint32_t* __restrict__ keys,
+                                                         uint32_t* __restrict__ hist,
+                                                         uint32_t* __restrict__ grp_acc,
+                                                         uint32_t* __restrict__ grp_clear_a,
+                                                         uint32_t* __restrict__ grp_clear_b,
+                                                         uint32_t n_group_words, uint32_t n_clear_a_words,
+                                                         uint32_t* __restrict__ seg_groups, uint32_t n_seg_groups,
+                                                         uint32_t key_bits) {
+    __shared__ uint32_t lh[CM_RADIX];
+    const uint32_t tile = blockIdx.x;
+    for (uint32_t k = tile * CM_BLOCK + threadIdx.x; k < n_seg_groups * 32; k += gridDim.x * CM_BLOCK) seg_groups[k] = 0;
+    for (uint32_t k = tile * CM_BLOCK + threadIdx.x; k < 3 * n_group_words; k += gridDim.x * CM_BLOCK) grp_clear_b[k] = 0;
+    for (uint32_t k = tile * CM_BLOCK + threadIdx.x; k < n_clear_a_words; k += gridDim.x * CM_BLOCK) grp_clear_a[k] = 0;
+    if (tile == 0 && threadIdx.x == 0) {
+        st->status = CM_DEV_OK;
+        st->key_bits = key_bits;
+        st->n_passes = (key_bits + CM_RADIX_BITS - 1) / CM_RADIX_BITS;
+    }
+    const uint32_t s = sensor_of_tile(fd, tile);
+    const CmSensorDev& sd = fd->s[s];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t slot0 = tile * CM_TILE + w * (64 * CM_ITEMS) + lane;
+    const uint32_t first = slot0 - sd.base;
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < CM_ITEMS; ++r) {
+        const uint32_t i = first + r * 64;
+        uint32_t key = CM_INVALID_KEY;
+        if (i < sd.n) {
+            key = *reinterpret_cast<const uint32_t*>(sd.data + static_cast<size_t>(i) * 32);
+            atomicAdd(&lh[key & (CM_RADIX - 1)], 1u);
+        }
+        keys[slot0 + r * 64] = key;
+    }
+    __syncthreads();
+    const uint32_t c = lh[threadIdx.x];
+    hist[static_cast<size_t>(tile) * CM_RADIX + threadIdx.x] = c;
+    if (c) atomicAdd(&grp_acc[static_cast<size_t>(tile / CM_GROUP) * CM_RADIX + threadIdx.x], c);
+}
+
+// Threshold + divide + compaction of merged entries (two launches around k_scan_counts).
+__global__ __launch_bounds__(CM_BLOCK) void k_table_finish(const float4* __restrict__ entries, uint32_t n,
+                                                           uint32_t min_pts, uint32_t* __restrict__ tile_counts,
+                                                           float4* __restrict__ out, uint32_t* __restrict__ out_key,
+                                                           uint32_t* __restrict__ out_cnt, int write) {
+    __shared__ uint32_t lds[CM_WAVES];
+    const uint32_t need = min_pts > 1 ? min_pts : 1u;
+    uint32_t slot = write ? tile_counts[blockIdx.x] : 0u;
+    uint32_t total = 0;
+    for (int r = 0; r < CM_ITEMS; ++r) {            // rounds in order, threads in order: stable
+        const uint32_t i = blockIdx.x * CM_TILE + r * CM_BLOCK + threadIdx.x;
+        bool keep = false;
+        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+        if (i < n) {
+            lo = entries[2 * static_cast<size_t>(i)];
+            hi = entries[2 * static_cast<size_t>(i) + 1];
+            keep = __float_as_uint(lo.y) >= need;
+        }
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_u32(keep ? 1u : 0u, lds, &tot);
+        if (write && keep) {
+            const uint32_t cnt = __float_as_uint(lo.y);
+            const float c = static_cast<float>(cnt);
+            out[slot + ex] = make_float4(__fdiv_rn(lo.z, c), __fdiv_rn(lo.w, c), __fdiv_rn(hi.x, c), __fdiv_rn(hi.y, c));
+            if (out_key) { out_key[slot + ex] = __float_as_uint(lo.x); out_cnt[slot + ex] = cnt; }
+        }
+        slot += tot;
+        total += tot;
+    }
+    if (!write && threadIdx.x == 0) tile_counts[blockIdx.x] = total;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1122,13 +1223,37 @@ void cmk_seg_count(hipStream_t s, const CmFrameState* st, const uint32_t* keys_a
                    uint32_t* counts, uint32_t* group_counts, uint32_t min_pts, uint32_t n_seg_tiles) {
     CM_LAUNCH(k_seg_count, n_seg_tiles, CM_BLOCK, s, st, keys_a, keys_b, counts, group_counts, min_pts);
 }
-void cmk_seg_reduce(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next,
+void cmk_seg_reduce(hipStream_t s, int mode, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next,
                     uint32_t* host_state, const uint32_t* keys_a, const uint32_t* vals_a,
                     const uint32_t* keys_b, const uint32_t* vals_b, const uint32_t* counts,
                     const uint32_t* group_counts, void* out, uint32_t* out_key, uint32_t* out_cnt,
                     uint32_t n_seg_tiles) {
-    CM_LAUNCH(k_seg_reduce, n_seg_tiles, CM_BLOCK, s, fd, st, st_next, host_state, keys_a, vals_a, keys_b,
-              vals_b, counts, group_counts, reinterpret_cast<float4*>(out), out_key, out_cnt);
+    float4* o = reinterpret_cast<float4*>(out);
+    if (mode == SEG_CENTROIDS)
+        CM_LAUNCH(k_seg_reduce<SEG_CENTROIDS>, n_seg_tiles, CM_BLOCK, s, fd, st, st_next, host_state, keys_a, vals_a,
+                  keys_b, vals_b, counts, group_counts, o, out_key, out_cnt);
+    else if (mode == SEG_PARTIAL)
+        CM_LAUNCH(k_seg_reduce<SEG_PARTIAL>, n_seg_tiles, CM_BLOCK, s, fd, st, st_next, host_state, keys_a, vals_a,
+                  keys_b, vals_b, counts, group_counts, o, out_key, out_cnt);
+    else
+        CM_LAUNCH(k_seg_reduce<SEG_TABLES>, n_seg_tiles, CM_BLOCK, s, fd, st, st_next, host_state, keys_a, vals_a,
+                  keys_b, vals_b, counts, group_counts, o, out_key, out_cnt);
+}
+void cmk_table_keys(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* keys, uint32_t* hist,
+                    uint32_t* grp_acc, uint32_t* grp_clear_a, uint32_t* grp_clear_b, uint32_t n_group_words,
+                    uint32_t n_clear_a_words, uint32_t* seg_groups, uint32_t n_seg_groups, uint32_t key_bits,
+                    uint32_t n_tiles) {
+    CM_LAUNCH(k_table_keys, n_tiles, CM_BLOCK, s, fd, st, keys, hist, grp_acc, grp_clear_a, grp_clear_b,
+              n_group_words, n_clear_a_words, seg_groups, n_seg_groups, key_bits);
+}
+void cmk_table_finish(hipStream_t s, const void* entries, uint32_t n, uint32_t min_pts, uint32_t* tile_counts,
+                      uint32_t* total, void* out, uint32_t* out_key, uint32_t* out_cnt) {
+    const uint32_t nt = (n + CM_TILE - 1) / CM_TILE;
+    if (nt == 0) return;
+    const float4* e = reinterpret_cast<const float4*>(entries);
+    CM_LAUNCH(k_table_finish, nt, CM_BLOCK, s, e, n, min_pts, tile_counts, reinterpret_cast<float4*>(out), out_key, out_cnt, 0);
+    CM_LAUNCH(k_scan_counts, 1, CM_BLOCK, s, tile_counts, nt, total);
+    CM_LAUNCH(k_table_finish, nt, CM_BLOCK, s, e, n, min_pts, tile_counts, reinterpret_cast<float4*>(out), out_key, out_cnt, 1);
 }
 void cmk_merged(hipStream_t s, const CmFrameDev* fd, uint32_t* tile_counts, uint32_t* total, void* out,
                 uint32_t n_tiles) {

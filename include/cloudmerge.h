@@ -156,6 +156,33 @@ CM_API const char* cm_status_string(int status);
 CM_API const char* cm_last_error(cm_ctx* ctx);
 CM_API int cm_version(void);
 
+/* ---- multi-GPU single fused cloud (nothing like it exists in the reference) ---
+ * One process per GPU. Each rank voxelises ITS sensors into a partial table of per-voxel sums
+ * (thresholding deferred: a voxel may hold one point on each of two GPUs), the host all-gathers the
+ * tables (RCCL over xGMI), and the merge re-sorts the concatenated entries by voxel index, adds
+ * them in rank order (deterministic), applies min_points_per_voxel and divides.
+ * All ranks must index the SAME grid: the crop box fixes it when it fits PCL's int32 index;
+ * otherwise pass the bounds of the whole fused cloud (cm_local_bounds on every rank, min/max
+ * all-reduced by the host) as global_min_max = {min x,y,z, max x,y,z}. */
+typedef struct cm_partial_entry {   /* 32 bytes */
+    uint32_t key;                   /* linear voxel index in the shared grid (PCL order) */
+    uint32_t count;
+    float sx, sy, sz, si;           /* fp32 sums, stable point order */
+    uint32_t _pad[2];
+} cm_partial_entry;
+/* fp32 min/max of this rank's transformed (+cropped) points; does not consume the clouds. */
+CM_API int cm_local_bounds(cm_ctx* ctx, const cm_params* p, float min_xyz[3], float max_xyz[3], uint64_t* n_valid);
+/* Like cm_merge_voxelize but stops before thresholding/division. res->n_out = table entries. */
+CM_API int cm_merge_partial(cm_ctx* ctx, const cm_params* p, const float* global_min_max, cm_result* res);
+CM_API int cm_partial_device(cm_ctx* ctx, const void** dev_entries, uint64_t* n_entries);
+/* dst may be host or device memory (e.g. the send buffer of the all-gather). */
+CM_API int cm_partial_copy(cm_ctx* ctx, cm_partial_entry* dst, uint64_t capacity);
+/* Merge n_tables tables (16-byte aligned device pointers, rank order) into the context's result
+ * buffer (cm_result_copy / cm_result_copy_cells read it; cells need the grid of the ranks'
+ * cm_merge_partial results). Synchronous. res->n_merged = distinct voxels, res->n_out = kept. */
+CM_API int cm_merge_tables(cm_ctx* ctx, const void* const* dev_tables, const uint64_t* n_entries,
+                           uint32_t n_tables, const cm_params* p, cm_result* res);
+
 /* ---- host memory helpers (pinned staging for PointCloud2 payloads) --------------------------- */
 CM_API int cm_host_alloc(void** ptr, size_t bytes);
 CM_API int cm_host_free(void* ptr);

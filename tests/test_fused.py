@@ -1,0 +1,179 @@
+"""Single fused cloud across GPUs: the table exchange on CPU with gloo
+(world_size 2), and on the GPU two contexts standing in for two ranks."""
+import multiprocessing as mp
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from cloud_merger_amd import fused, synth
+from cloud_merger_amd.capi import ENTRY_DTYPE
+from cloud_merger_amd.types import MergeParams
+from oracle import np_oracle, oracle
+from tests.util import assert_centroids_close, xyzi_of
+
+
+def crop_grid(params):
+    inv = np.float32(1) / np.asarray(params.leaf, dtype=np.float32)
+    lo = np.floor(np.asarray(params.crop_min, np.float32) * inv).astype(np.int64)
+    hi = np.floor(np.asarray(params.crop_max, np.float32) * inv).astype(np.int64)
+    return lo, hi - lo + 1
+
+
+def cpu_partial_table(sensors, params):
+    """What cm_merge_partial produces, restated with numpy (crop-box grid)."""
+    xyz, inten = np_oracle.merge(sensors, params)
+    lo, div = crop_grid(params)
+    c = np_oracle.cells(xyz, params.leaf) - lo
+    key = (c[:, 0] + c[:, 1] * div[0] + c[:, 2] * div[0] * div[1]).astype(np.uint32)
+    order = np.argsort(key, kind="stable")
+    key, vals = key[order], np.concatenate([xyz, inten[:, None]], axis=1)[order]
+    head = np.flatnonzero(np.r_[True, key[1:] != key[:-1]]) if len(key) else np.zeros(0, np.int64)
+    t = np.zeros(len(head), dtype=ENTRY_DTYPE)
+    if len(head):
+        sums = np.add.reduceat(vals.astype(np.float64), head, axis=0).astype(np.float32)
+        t["key"], t["count"] = key[head], np.diff(np.r_[head, len(key)])
+        t["sx"], t["sy"], t["sz"], t["si"] = sums[:, 0], sums[:, 1], sums[:, 2], sums[:, 3]
+    return t
+
+
+def decode_cells(keys, params):
+    lo, div = crop_grid(params)
+    k = keys.astype(np.int64)
+    return np.stack([k % div[0] + lo[0], (k // div[0]) % div[1] + lo[1], k // (div[0] * div[1]) + lo[2]], axis=1)
+
+
+def test_numpy_table_merge_matches_oracle():
+    sensors, params = synth.config3(n_per_sensor=30_000, n_sensors=6, min_pts=2, leaf=0.1)
+    tables = [cpu_partial_table([sensors[s] for s in fused.shard_sensors(6, r, 3)], params) for r in range(3)]
+    keys, cnt, cent = fused.merge_tables_numpy(tables, params.min_points_per_voxel)
+    st, _, ref, rep = oracle.merge_voxelize(sensors, params, stable=True)
+    assert st == oracle.OK and len(keys) == rep.n_out
+    assert np.array_equal(decode_cells(keys, params), rep.cells) and np.array_equal(cnt, rep.counts)
+    assert_centroids_close(cent, xyzi_of(ref))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gloo_rank(rank, world, port, q):
+    try:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        sensors, params = synth.config3(n_per_sensor=20_000, n_sensors=4, min_pts=2, leaf=0.1)
+        mine = [sensors[s] for s in fused.shard_sensors(len(sensors), rank, world)]
+        # bounds exchange (what ranks do when no crop box fixes the grid)
+        xyz, _ = np_oracle.merge(mine, params)
+        b = fused.allreduce_bounds(dist, xyz.min(axis=0), xyz.max(axis=0), len(xyz))
+        allxyz, _ = np_oracle.merge(sensors, params)
+        assert np.array_equal(b[:3], allxyz.min(axis=0)) and np.array_equal(b[3:], allxyz.max(axis=0))
+        # table exchange
+        t = cpu_partial_table(mine, params)
+        tt = torch.from_numpy(t.view(np.int32).reshape(-1, 8).copy())
+        gathered, counts = fused.allgather_tables(dist, tt, len(t), world)
+        tables = [gathered[r][:counts[r]].numpy().copy().view(ENTRY_DTYPE).reshape(-1) for r in range(world)]
+        assert counts[rank] == len(t) and np.array_equal(tables[rank], t)
+        keys, cnt, cent = fused.merge_tables_numpy(tables, params.min_points_per_voxel)
+        st, _, ref, rep = oracle.merge_voxelize(sensors, params, stable=True)
+        assert len(keys) == rep.n_out and np.array_equal(decode_cells(keys, params), rep.cells)
+        assert np.array_equal(cnt, rep.counts)
+        assert_centroids_close(cent, xyzi_of(ref))
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:                      # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_table_exchange_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q, port, world = ctx.Queue(), _free_port(), 2
+    procs = [ctx.Process(target=_gloo_rank, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+# ---- GPU: two contexts as two ranks -----------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("crop", [True, False])
+def test_two_rank_fused_cloud_on_one_gpu(crop):
+    from cloud_merger_amd import capi
+    if crop:
+        sensors, params = synth.config3(n_per_sensor=150_000, n_sensors=6, min_pts=2, leaf=0.05)
+    else:
+        sensors, params = synth.config2(n_per_sensor=100_000, n_sensors=4, min_pts=2)
+    world = 2
+    cms, parts = [], []
+    n_total = sum(s.n for s in sensors)
+    for r in range(world):
+        cm = capi.CloudMerger(max_points_total=n_total, max_sensors=len(sensors), flags=capi.FLAG_OCCUPANCY)
+        for k, s in enumerate(fused.shard_sensors(len(sensors), r, world)):
+            cm.set_transform(k, sensors[s].q_xyzw, sensors[s].t_xyz)
+            cm.submit(k, sensors[s])
+        cms.append(cm)
+    bounds = None
+    if not crop:
+        lb = [cm.local_bounds(params) for cm in cms]
+        bounds = np.concatenate([np.min([b[0] for b in lb], axis=0), np.max([b[1] for b in lb], axis=0)])
+    for cm in cms:
+        res = cm.merge_partial(params, bounds)
+        assert res.status == capi.OK
+        parts.append(cm.partial_device())
+    # sanity of one table against the numpy restatement (crop grid only)
+    if crop:
+        t0 = cms[0].partial(parts[0][1])
+        ref0 = cpu_partial_table([sensors[s] for s in fused.shard_sensors(len(sensors), 0, world)], params)
+        assert np.array_equal(t0["key"], ref0["key"]) and np.array_equal(t0["count"], ref0["count"])
+    res = cms[0].merge_tables([p[0] for p in parts], [p[1] for p in parts], params)
+    out = cms[0].result(res.n_out)
+    cells, counts = cms[0].cells(res.n_out)
+    st, _, ref, rep = oracle.merge_voxelize(sensors, params, stable=True)
+    assert res.status == capi.OK and res.n_out == rep.n_out
+    assert np.array_equal(cells, rep.cells) and np.array_equal(counts, rep.counts)
+    got = np.stack([out["x"], out["y"], out["z"], out["intensity"]], axis=1)
+    assert_centroids_close(got, xyzi_of(ref))
+    for cm in cms:
+        cm.close()
+
+
+_WORLD1_SCRIPT = r"""
+import sys
+import torch                                   # torch first: one HIP runtime per process (its bundled one)
+sys.path.insert(0, sys.argv[1])
+from cloud_merger_amd import capi, fused, synth
+sensors, params = synth.config3(n_per_sensor=80_000, n_sensors=4, min_pts=2, leaf=0.05)
+n_total = sum(s.n for s in sensors)
+with capi.CloudMerger(max_points_total=n_total, max_sensors=4, flags=capi.FLAG_OCCUPANCY) as cm:
+    cm.submit_all(sensors)
+    a = cm.merge_voxelize(params)
+    plain = cm.result(a.n_out)
+    cm.submit_all(sensors)
+    b = fused.fused_cloud(cm, params, None, 0, 1, torch.device("cuda", 0))
+    viaf = cm.result(b.n_out)
+assert a.status == 0 and b.status == 0 and a.n_out == b.n_out > 0, (a.n_out, b.n_out)
+assert plain.tobytes() == viaf.tobytes()
+print("ok", a.n_out)
+"""
+
+
+@pytest.mark.gpu
+def test_fused_cloud_world1_equals_plain_path():
+    """fused.fused_cloud with torch tensors as exchange buffers (own process: a process that uses
+    torch and the library must import torch first so both share one HIP runtime)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _WORLD1_SCRIPT, root], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
