@@ -167,9 +167,20 @@ def main():
                     "us_per_frame": 1e3 * acc[n][0] / nf} for n in order]
         dom = max(kernels, key=lambda k: k["us_per_frame"])
         achieved = b_alg / (t_device_ms * 1e-3) / 1e9
+        # HBM traffic per frame from the PMC counters: collected by scripts/pmc_traffic.sh in separate
+        # rocprofv3 --pmc passes of this same command and committed under profiles/ (counters cannot
+        # be read from inside the process). gfx950's FETCH_SIZE counts wide reads at half their
+        # bytes, so the corrected figure (fetch x2 + write) is quoted; raw kept beside it.
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", f"r1_pmc_traffic_cfg{args.config}_minpts{args.min_pts}.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            traffic = tj["traffic_high"]
+            traffic_src = {"file": os.path.relpath(tpath, ROOT), "fetch_raw": tj["fetch_raw"], "write": tj["write"],
+                           "fetch_corrected_x2": tj["fetch_x2"], "frames_averaged": tj["frames"]}
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "scope": "whole frame pipeline: algorithmic bytes 16*N_in + 16*M over first-kernel-start to "
                      "last-kernel-end (HIP events on the launch stream)",
             "algorithmic_bytes_per_frame": b_alg, "t_device_ms": t_device_ms,
@@ -178,6 +189,27 @@ def main():
         out_gpu = cmp.result(r.n_out)
         cells_gpu, counts_gpu = cmp.cells(r.n_out)
         cmp.close()
+
+        # PCIe-inclusive figure (never `value`): PointCloud2 payloads in host memory in, compact
+        # result in host memory out, through cm_submit_cloud / cm_result_copy.
+        if world == 1:
+            cme = capi.CloudMerger(max_points_total=n_in, max_sensors=len(sensors), device=local_rank)
+            for k, s in enumerate(sensors):
+                cme.set_transform(k, s.q_xyzw, s.t_xyz)
+            t_e2e = []
+            for it in range(7):
+                torch.cuda.synchronize()
+                ta = time.perf_counter()
+                for k, s in enumerate(sensors):
+                    cme.submit(k, s)
+                re = cme.merge_voxelize(params)
+                host_out = cme.result(re.n_out)
+                t_e2e.append(time.perf_counter() - ta)
+            cme.close()
+            e2e = float(np.median(t_e2e[2:]))
+            out["config"]["e2e_host_buffers"] = {"ms_per_step": 1e3 * e2e, "points_per_s": n_in / e2e,
+                                                 "note": "pageable host payloads -> HBM -> result in host memory "
+                                                         "(H2D + D2H over PCIe included); reported beside, never as, value"}
 
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle
