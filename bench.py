@@ -180,6 +180,8 @@ def main():
         nf = args.profile_frames
         t_device_ms = float(np.median(dev_ms))
         b_alg = 16.0 * n_in + 16.0 * n_out              # read each point once, write each voxel once
+        # avg_us is event-to-event: the kernel plus the dependent-launch gap behind it (1.5-3 us);
+        # rocprofv3's kernel_stats.csv shows the kernels alone.
         kernels = [{"name": n, "launches_per_frame": acc[n][1] / nf, "avg_us": 1e3 * acc[n][0] / acc[n][1],
                     "us_per_frame": 1e3 * acc[n][0] / nf} for n in order]
         dom = max(kernels, key=lambda k: k["us_per_frame"])

@@ -125,6 +125,15 @@ def test_config3_full_size_properties():
     assert g["res"].n_in == 16_000_000
 
 
+def test_large_frame_group_paths():
+    """> 8 M valid points: more than 64 tile groups (k_gscan) and more than 4096 sorted tiles
+    (kept-voxel totals per group of tiles) — the code paths of cfg5-sized frames."""
+    sensors, params = synth.config2(n_per_sensor=3_000_000, n_sensors=3, min_pts=2)
+    params.leaf = (0.04,) * 3
+    g, rep = check_against_oracle(sensors, params, exact_small_runs=True)
+    assert g["res"].n_merged == 9_000_000
+
+
 def test_reference_parameters():
     """The reference's own settings: leaf 0.1, min 2 points, ROI crop (Parameter.h:27-35), 6 sensors."""
     sensors, _ = synth.config3(n_per_sensor=120_000, n_sensors=6)
