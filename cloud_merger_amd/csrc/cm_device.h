@@ -17,7 +17,7 @@
 #define CM_INVALID_KEY 0xFFFFFFFFu
 
 #define CM_GROUP 32           // tiles per group total in the radix passes
-#define CM_DIRECT_GROUPS 64   // up to this many groups k_scatter sums the group totals itself
+#define CM_DIRECT_GROUPS 64   // up to this many groups (8 M slots) k_scatter sums the group totals itself
 
 #define CM_SEG_TILE 2048      // sorted items per workgroup in the centroid kernel
 #define CM_SEG_ITEMS 8

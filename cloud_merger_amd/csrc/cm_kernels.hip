@@ -431,25 +431,41 @@ __global__ __launch_bounds__(CM_BLOCK) void k_hist(const CmFrameState* __restric
     if (c) atomicAdd(&grp[static_cast<size_t>(blockIdx.x / CM_GROUP) * CM_RADIX + threadIdx.x], c);
 }
 
-// Large frames only (more than CM_DIRECT_GROUPS groups): group totals -> exclusive prefix over
-// the groups, in place, plus the digit totals. One workgroup, thread d owns digit d.
-__global__ __launch_bounds__(CM_BLOCK) void k_gscan(const CmFrameState* __restrict__ st,
-                                                    uint32_t* __restrict__ grp,
-                                                    uint32_t* __restrict__ totals,
-                                                    uint32_t pass, uint32_t n_groups) {
+// Very large frames only (more than CM_DIRECT_GROUPS groups): group totals -> exclusive prefix
+// over the groups, in place, plus the digit totals. One workgroup of 1024 threads: four chunks of
+// groups are scanned side by side, thread (c, d) owning digit d of chunk c.
+__global__ __launch_bounds__(1024) void k_gscan(const CmFrameState* __restrict__ st,
+                                                uint32_t* __restrict__ grp,
+                                                uint32_t* __restrict__ totals,
+                                                uint32_t pass, uint32_t n_groups) {
+    __shared__ uint32_t chunk_total[4][CM_RADIX];
     if (st->status != CM_DEV_OK || pass >= st->n_passes) return;
-    uint32_t run = 0;
-    for (uint32_t g = 0; g < n_groups; g += 8) {
+    const uint32_t d = threadIdx.x & (CM_RADIX - 1), c = threadIdx.x >> 8;
+    const uint32_t per = (n_groups + 3) / 4;
+    const uint32_t g0 = c * per, g1 = min(g0 + per, n_groups);
+    uint32_t sum = 0;
+    for (uint32_t g = g0; g < g1; g += 8) {
         uint32_t v[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = (g + q < n_groups) ? grp[static_cast<size_t>(g + q) * CM_RADIX + threadIdx.x] : 0u;
+        for (int q = 0; q < 8; ++q) v[q] = (g + q < g1) ? grp[static_cast<size_t>(g + q) * CM_RADIX + d] : 0u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sum += v[q];
+    }
+    chunk_total[c][d] = sum;
+    __syncthreads();
+    uint32_t run = 0;
+    for (uint32_t q = 0; q < c; ++q) run += chunk_total[q][d];
+    if (c == 3) totals[d] = run + sum;
+    for (uint32_t g = g0; g < g1; g += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (g + q < g1) ? grp[static_cast<size_t>(g + q) * CM_RADIX + d] : 0u;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            if (g + q < n_groups) grp[static_cast<size_t>(g + q) * CM_RADIX + threadIdx.x] = run;
+            if (g + q < g1) grp[static_cast<size_t>(g + q) * CM_RADIX + d] = run;
             run += v[q];
         }
     }
-    totals[threadIdx.x] = run;
 }
 
 // Lanes of the wave that hold the same 8-bit digit (among valid lanes).
@@ -1194,7 +1210,7 @@ void cmk_hist(hipStream_t s, const CmFrameState* st, const uint32_t* keys, uint3
 }
 void cmk_gscan(hipStream_t s, const CmFrameState* st, uint32_t* grp, uint32_t* totals, uint32_t pass,
                uint32_t n_groups) {
-    CM_LAUNCH(k_gscan, 1, CM_BLOCK, s, st, grp, totals, pass, n_groups);
+    CM_LAUNCH(k_gscan, 1, 1024, s, st, grp, totals, pass, n_groups);
 }
 void cmk_scatter(hipStream_t s, CmFrameState* st, const uint32_t* keys_in, const uint32_t* vals_in,
                  uint32_t* keys_out, uint32_t* vals_out, const uint32_t* hist, const uint32_t* grp,
