@@ -538,7 +538,14 @@ __global__ __launch_bounds__(CM_BLOCK, 4) void k_scatter(CmFrameState* __restric
     __shared__ uint32_t lds[CM_WAVES];
     __shared__ uint32_t s_tile_valid;
     if (st->status != CM_DEV_OK || pass >= st->n_passes) return;
-    const uint32_t tile = blockIdx.x;
+    // Workgroups are dealt round-robin over the 8 XCDs (speed only, never correctness): give each
+    // XCD a contiguous range of tiles, so the digit runs of neighbouring tiles — adjacent in the
+    // output — meet in one L2 instead of leaving as partial lines from eight.
+    uint32_t tile = blockIdx.x;
+    {
+        const uint32_t per = gridDim.x / 8;
+        if (blockIdx.x < per * 8) tile = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    }
     const uint32_t shift = pass * CM_RADIX_BITS;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t first = tile * CM_TILE + w * (64 * CM_ITEMS) + lane;
