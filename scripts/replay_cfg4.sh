@@ -1,0 +1,9 @@
+#!/bin/bash
+# BASELINE config 4: 4 sensors, 100 frames @10 Hz recorded as .pcd (synthesised: the reference ships
+# no data), replayed through the C++ CloudMergerNode. One GPU here; `--shard r/N` per rank on N GPUs.
+set -e
+SEQ=/tmp/cfg4_seq
+python -m cloud_merger_amd.replay_data $SEQ --frames 100 --sensors 4 > /dev/null
+make -C cloud_merger_amd/host -s
+./cloud_merger_amd/host/bin/cloudmerge_replay --dir $SEQ --sensors 4 --frames 100 --leaf 0.05 --min-pts 2
+./cloud_merger_amd/host/bin/cloudmerge_replay --dir $SEQ --sensors 4 --frames 100 --leaf 0.1 --min-pts 2 --crop -15 -5 -0.5 60 5 3
