@@ -385,7 +385,15 @@ int wait_frame(cm_ctx* c, cm_result* res) {
         HIP_TRY(c, hipEventSynchronize(c->ev_done));
         c->in_flight.store(false);
         const CmFrameState& h = *c->h_state;
-        if (h.err) { c->pending = false; return fail(c, CM_INTERNAL, "device reported an internal error"); }
+        if (h.err) {
+            c->pending = false;
+            if (h.err == 2 && c->lds_rank) {
+                // The sorted keys were not sorted: stop trusting lane-ordered LDS adds on this device.
+                c->lds_rank = false;
+                return fail(c, CM_INTERNAL, "radix sort check failed with LDS-add ranking; switched to ballot ranking, resubmit the frame");
+            }
+            return fail(c, CM_INTERNAL, "device reported an internal error");
+        }
         r.status = h.status;
         r.bounds_from_crop = c->from_crop ? 1u : 0u;
         for (int a = 0; a < 3; ++a) {
@@ -858,6 +866,10 @@ int cm_merge_tables(cm_ctx* c, const void* const* dev_tables, const uint64_t* n_
     HIP_TRY(c, hipStreamSynchronize(st));
     c->cur ^= 1;
     const CmFrameState& h = *c->h_state;
+    if (h.err) {
+        if (h.err == 2 && c->lds_rank) c->lds_rank = false;
+        return fail(c, CM_INTERNAL, "device reported an internal error while merging tables");
+    }
     const uint32_t n_merged = h.status == CM_OK ? h.n_out : 0;       // distinct voxels over all tables
     uint32_t n_out = 0;
     if (n_merged) {

@@ -20,7 +20,7 @@ void cmk_scatter(hipStream_t s, CmFrameState* st, const uint32_t* keys_in, const
                  const uint32_t* totals, uint32_t pass, uint32_t n_tiles, uint32_t n_groups,
                  uint32_t n_padded, bool lds_rank);
 void cmk_probe_lds_order(hipStream_t s, uint32_t* violations, uint32_t rounds);
-void cmk_seg_count(hipStream_t s, const CmFrameState* st, const uint32_t* keys_a, const uint32_t* keys_b,
+void cmk_seg_count(hipStream_t s, CmFrameState* st, const uint32_t* keys_a, const uint32_t* keys_b,
                    uint32_t* counts, uint32_t* group_counts, uint32_t min_pts, uint32_t n_seg_tiles);
 // mode: 0 points -> centroids, 1 points -> partial entries, 2 partial entries -> merged entries
 void cmk_seg_reduce(hipStream_t s, int mode, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next,

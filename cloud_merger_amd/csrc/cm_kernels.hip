@@ -673,11 +673,12 @@ __device__ __forceinline__ const uint32_t* pick(const CmFrameState* st, const ui
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3a: kept voxels per tile of the sorted keys (+ totals per group of CM_SEG_GROUP tiles). A run is
+// K3a: kept voxels per tile of the sorted keys (+ totals per group of CM_SEG_GROUP tiles), and a
+// check that the keys really are sorted (st->err = 2 otherwise). A run is
 // owned by the tile holding its head; it is kept iff it reaches min_points_per_voxel (A.4 step 7),
 // i.e. keys[head + min_pts - 1] == key.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(CM_BLOCK) void k_seg_count(const CmFrameState* __restrict__ st,
+__global__ __launch_bounds__(CM_BLOCK) void k_seg_count(CmFrameState* __restrict__ st,
                                                         const uint32_t* __restrict__ keys_a,
                                                         const uint32_t* __restrict__ keys_b,
                                                         uint32_t* __restrict__ counts,
@@ -690,12 +691,15 @@ __global__ __launch_bounds__(CM_BLOCK) void k_seg_count(const CmFrameState* __re
     if (base >= n) return;
     const uint32_t* __restrict__ keys = pick(st, keys_a, keys_b);
     uint32_t cnt = 0;
+    bool unsorted = false;
 #pragma unroll
     for (int j = 0; j < CM_SEG_ITEMS; ++j) {
         const uint32_t i = base + j * CM_BLOCK + threadIdx.x;
         if (i < n) {
             const uint32_t k = keys[i];
-            const bool head = (i == 0) || (keys[i - 1] != k);
+            const uint32_t kp = (i == 0) ? 0u : keys[i - 1];
+            unsorted = unsorted || (i > 0 && kp > k);   // every adjacent pair is seen here: free check of the sort
+            const bool head = (i == 0) || (kp != k);
             bool keep = head;
             if (head && min_pts > 1) {
                 const uint32_t e = i + min_pts - 1;
@@ -704,6 +708,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_seg_count(const CmFrameState* __re
             cnt += keep ? 1u : 0u;
         }
     }
+    if (unsorted) st->err = 2u;
     const uint32_t tot = block_sum_u32(cnt, lds);
     if (threadIdx.x == 0) {
         counts[blockIdx.x] = tot;
@@ -962,13 +967,17 @@ __global__ __launch_bounds__(CM_BLOCK) void k_seg_reduce(const CmFrameDev* __res
     // Wave64 segmented suffix scan of `pre`: S[t] = pre[t] + (has_head[t] ? 0 : S[t+1]).
     Acc S = pre;
     uint32_t flag = has_head ? 1u : 0u;
+    // Common case: every lane of the wave has a head in its chunk, so nothing propagates further
+    // than one lane (S[t] = pre[t]) and the scan is skipped (wave-uniform branch).
+    if (__ballot(has_head) != ~0ull) {
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const Acc o = acc_shfl_down(S, d);
-        const uint32_t of = __shfl_down(flag, d);
-        if (lane + d < 64 && !flag) {
-            if (S.c == 0) S = o; else if (o.c) acc_add(S, o);
-            flag |= of;
+        for (int d = 1; d < 64; d <<= 1) {
+            const Acc o = acc_shfl_down(S, d);
+            const uint32_t of = __shfl_down(flag, d);
+            if (lane + d < 64 && !flag) {
+                if (S.c == 0) S = o; else if (o.c) acc_add(S, o);
+                flag |= of;
+            }
         }
     }
     if (lane == 0) {
@@ -1242,7 +1251,7 @@ void cmk_scatter(hipStream_t s, CmFrameState* st, const uint32_t* keys_in, const
 void cmk_probe_lds_order(hipStream_t s, uint32_t* violations, uint32_t rounds) {
     CM_LAUNCH(k_probe_lds_order, 512, CM_BLOCK, s, violations, rounds);
 }
-void cmk_seg_count(hipStream_t s, const CmFrameState* st, const uint32_t* keys_a, const uint32_t* keys_b,
+void cmk_seg_count(hipStream_t s, CmFrameState* st, const uint32_t* keys_a, const uint32_t* keys_b,
                    uint32_t* counts, uint32_t* group_counts, uint32_t min_pts, uint32_t n_seg_tiles) {
     CM_LAUNCH(k_seg_count, n_seg_tiles, CM_BLOCK, s, st, keys_a, keys_b, counts, group_counts, min_pts);
 }

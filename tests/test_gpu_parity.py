@@ -341,3 +341,35 @@ def test_profile_stage_times():
     names = [n for n, _ in stages]
     assert "k_keys" in names and ("k_radix_pass" in names or "k_scatter" in names) and "k_seg_reduce" in names
     assert res.device_ms > 0 and all(ms >= 0 for _, ms in stages)
+
+
+_BALLOT_SCRIPT = r"""
+import sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from cloud_merger_amd import capi, synth
+from oracle import oracle
+sensors, params = synth.config2(n_per_sensor=120_000, min_pts=2)
+with capi.CloudMerger(max_points_total=480_000, max_sensors=4, flags=capi.FLAG_OCCUPANCY) as cm:
+    cm.submit_all(sensors)
+    res = cm.merge_voxelize(params)
+    cells, counts = cm.cells(res.n_out)
+st, _, ref, rep = oracle.merge_voxelize(sensors, params, stable=True)
+assert res.status == 0 and res.n_out == rep.n_out
+assert np.array_equal(cells, rep.cells) and np.array_equal(counts, rep.counts)
+print("flags", res.path_flags)
+"""
+
+
+@pytest.mark.parametrize("force", ["0", "1"])
+def test_both_ranking_variants(force):
+    """CM_LDS_RANK=0 forces the ballot-match ranking, =1 the LDS-add ranking (normally chosen by
+    the device probe at cm_create); both must give the oracle's occupancy."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CM_LDS_RANK=force)
+    r = subprocess.run([sys.executable, "-c", _BALLOT_SCRIPT, root], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip().endswith("flags " + force)
