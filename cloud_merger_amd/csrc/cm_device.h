@@ -21,7 +21,7 @@
 
 #define CM_SEG_TILE 2048      // sorted items per workgroup in the centroid kernel
 #define CM_SEG_ITEMS 8
-#define CM_MINMAX_BLOCKS 512  // workgroups (= partial records) of the min/max pass
+#define CM_MINMAX_BLOCKS 1024 // workgroups (= partial records) of the min/max pass
 #define CM_SEG_GROUP 256      // sorted tiles per kept-voxel group total (== CM_BLOCK)
 #define CM_SEG_DIRECT_TILES 4096  // up to this many sorted tiles the per-tile counts are summed directly
 
