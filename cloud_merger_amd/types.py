@@ -9,6 +9,8 @@ REF_VOXEL_SIZE = 0.1
 REF_POINTS_PER_VOXEL = 2
 REF_ROI_MIN = (-15.0, -5.0, -0.5)          # x: -roi_mid, y: -roi_width/2, z: roi_z_min
 REF_ROI_MAX = (60.0, 5.0, 3.0)             # x: roi_length-roi_mid, y: roi_width/2, z: roi_z_max
+REF_OUTLIER_RADIUS = 0.15                  # Parameter.h:23 (my_cloud_fusion/Parameter.h:15 uses 0.1)
+REF_OUTLIER_MIN_NEIGHBORS = 1              # Parameter.h:24
 
 # Compact device/wire layout used by the synthetic inputs: x,y,z,intensity float32.
 XYZI_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("intensity", "<f4")])
@@ -40,6 +42,9 @@ class MergeParams:
     crop_min: Optional[Sequence[float]] = None
     crop_max: Optional[Sequence[float]] = None
     required_sensor_mask: int = 0          # 0: every submitted sensor is required
+    # RadiusOutlierRemoval on the fused cloud before VoxelGrid (CloudFusionNode.h:74-85); None = off.
+    outlier_radius: Optional[float] = None
+    outlier_min_neighbors: int = 1
 
 
 def xyzi_cloud(xyz, intensity=None, **kw) -> SensorCloud:

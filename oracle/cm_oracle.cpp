@@ -14,6 +14,7 @@
 #include <cstring>
 #include <limits>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -147,6 +148,47 @@ size_t orc_crop(const orc_point* in, size_t n, const float mn[3], const float mx
     passthrough(r, offsetof(orc_point, x), mn[0], mx[0], r);
     std::copy(r.begin(), r.end(), out);
     return r.size();
+}
+
+size_t orc_radius_outlier_removal(const orc_point* in, size_t n, float radius, uint32_t min_neighbors,
+                                  orc_point* out, uint8_t* keep_mask) {
+    // Uniform hash grid with cells a little wider than the radius: every point within the radius
+    // lies in the 27 cells around the query. The grid only finds candidates; the test itself is
+    // the fp32 squared distance below.
+    const float r2 = static_cast<float>(static_cast<double>(radius) * static_cast<double>(radius));
+    const double cell = static_cast<double>(radius) * 1.001;
+    auto cid = [&](float v) { return static_cast<int64_t>(std::floor(static_cast<double>(v) / cell)); };
+    auto pack = [](int64_t i, int64_t j, int64_t k) {
+        return static_cast<uint64_t>((i + (1 << 20)) & 0x1FFFFF) | (static_cast<uint64_t>((j + (1 << 20)) & 0x1FFFFF) << 21) |
+               (static_cast<uint64_t>((k + (1 << 20)) & 0x1FFFFF) << 42);
+    };
+    std::unordered_map<uint64_t, std::vector<uint32_t>> grid;
+    grid.reserve(n);
+    for (size_t i = 0; i < n; ++i)
+        if (finite3(in[i])) grid[pack(cid(in[i].x), cid(in[i].y), cid(in[i].z))].push_back(static_cast<uint32_t>(i));
+    size_t o = 0;
+    for (size_t i = 0; i < n; ++i) {
+        bool keep = false;
+        if (finite3(in[i])) {
+            const int64_t ci = cid(in[i].x), cj = cid(in[i].y), ck = cid(in[i].z);
+            uint32_t k = 0;                                    // includes the query point itself
+            for (int dk = -1; dk <= 1 && k <= min_neighbors; ++dk)
+                for (int dj = -1; dj <= 1 && k <= min_neighbors; ++dj)
+                    for (int di = -1; di <= 1 && k <= min_neighbors; ++di) {
+                        auto it = grid.find(pack(ci + di, cj + dj, ck + dk));
+                        if (it == grid.end()) continue;
+                        for (uint32_t q : it->second) {
+                            const float dx = in[i].x - in[q].x, dy = in[i].y - in[q].y, dz = in[i].z - in[q].z;
+                            const float d2 = (dx * dx + dy * dy) + dz * dz;
+                            if (d2 < r2 && ++k > min_neighbors) break;
+                        }
+                    }
+            keep = k > min_neighbors;
+        }
+        if (keep_mask) keep_mask[i] = keep ? 1 : 0;
+        if (keep) out[o++] = in[i];
+    }
+    return o;
 }
 
 void orc_voxel_cells(const orc_point* in, size_t n, const float leaf[3], int32_t* ijk) {
@@ -294,6 +336,13 @@ int orc_merge_voxelize(const orc_sensor* sensors, int n_sensors, const orc_param
         if (s == 0) merged = st[s].cloud;
         else merged.insert(merged.end(), st[s].cloud.begin(), st[s].cloud.end());
         dense = dense && st[s].is_dense;
+    }
+    if (p->outlier_enable) {                                   // remove_outliers before voxelgrid
+        std::vector<orc_point> kept(merged.size());
+        kept.resize(orc_radius_outlier_removal(merged.data(), merged.size(), p->outlier_radius,
+                                               p->outlier_min_neighbors, kept.data(), nullptr));
+        merged.swap(kept);
+        dense = true;
     }
     auto t2 = clk::now();
     rep->t_concat_s = secs(t1, t2);

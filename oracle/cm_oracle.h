@@ -56,6 +56,10 @@ typedef struct orc_params {
     int32_t crop_enable;             /* getROI (:20-40) */
     float crop_min[3];               /* x,y,z inclusive */
     float crop_max[3];
+    int32_t outlier_enable;          /* RadiusOutlierRemoval on the fused cloud (CloudFusionNode.h:74-85,
+                                        cloud_fusion_node.cpp:72; live node :184-192) */
+    float outlier_radius;            /* setRadiusSearch (Parameter.h:23 / my_cloud_fusion Parameter.h:15) */
+    uint32_t outlier_min_neighbors;  /* setMinNeighborsInRadius (Parameter.h:24) */
 } orc_params;
 
 enum {
@@ -100,6 +104,15 @@ int orc_voxelgrid(const orc_point* in, size_t n, const float leaf[3], uint32_t m
                   orc_point* out, size_t* n_out, orc_report* rep,
                   int32_t* out_cells /* optional, 3 per voxel: absolute i,j,k */,
                   uint32_t* out_counts /* optional, points per kept voxel */);
+
+/* pcl::RadiusOutlierRemoval, keep_organized = false (PCL 1.8.1
+ * filters/impl/radius_outlier_removal.hpp, recalled): a point stays iff k > min_neighbors, where k
+ * counts the points of the cloud (itself included) with fp32 squared distance
+ * ((dx*dx + dy*dy) + dz*dz) < float(double(r)*double(r)) — FLANN's L2_Simple and its strict
+ * RadiusResultSet test (assumption: not verifiable here). Non-finite points never stay.
+ * Survivors keep their order. Returns the number written to out. */
+size_t orc_radius_outlier_removal(const orc_point* in, size_t n, float radius, uint32_t min_neighbors,
+                                  orc_point* out, uint8_t* keep_mask /* optional, n */);
 
 /* Absolute voxel cell of each point: floor(fl32(p * inv_leaf)) per axis (A.4 step 5). */
 void orc_voxel_cells(const orc_point* in, size_t n, const float leaf[3], int32_t* ijk /* 3n */);

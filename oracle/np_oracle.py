@@ -117,7 +117,31 @@ def merge(sensors, params):
     return np.concatenate(xs), np.concatenate(ins)
 
 
+def radius_outlier_mask(xyz, radius, min_neighbors=1):
+    """Independent restatement with scipy's kd-tree for candidates (float64, slightly enlarged radius) and
+    the fp32 test ((dx*dx + dy*dy) + dz*dz) < float(r*r) on the candidates."""
+    from scipy.spatial import cKDTree
+    r2 = F(float(radius) * float(radius))
+    ok = np.isfinite(xyz).all(axis=1)
+    idx = np.flatnonzero(ok)
+    keep = np.zeros(len(xyz), dtype=bool)
+    if len(idx) == 0:
+        return keep
+    pts = xyz[idx]
+    tree = cKDTree(pts.astype(np.float64))
+    cand = tree.query_ball_point(pts.astype(np.float64), float(radius) * 1.001)
+    for a, lst in enumerate(cand):
+        q = pts[np.asarray(lst, dtype=np.int64)]
+        d = pts[a] - q
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        keep[idx[a]] = int((d2 < r2).sum()) > min_neighbors        # k includes the point itself
+    return keep
+
+
 def merge_voxelize(sensors, params, sequential=False):
     xyz, inten = merge(sensors, params)
+    if getattr(params, "outlier_radius", None):
+        k = radius_outlier_mask(xyz, params.outlier_radius, params.outlier_min_neighbors)
+        xyz, inten = xyz[k], inten[k]
     return voxelgrid(xyz, inten, params.leaf, params.min_points_per_voxel,
                      params.downsample_all_data, sequential)

@@ -31,7 +31,8 @@ class _Sensor(C.Structure):
 class _Params(C.Structure):
     _fields_ = [("leaf", C.c_float * 3), ("min_points_per_voxel", C.c_uint32),
                 ("downsample_all_data", C.c_int32), ("crop_enable", C.c_int32),
-                ("crop_min", C.c_float * 3), ("crop_max", C.c_float * 3)]
+                ("crop_min", C.c_float * 3), ("crop_max", C.c_float * 3),
+                ("outlier_enable", C.c_int32), ("outlier_radius", C.c_float), ("outlier_min_neighbors", C.c_uint32)]
 
 
 class Report(C.Structure):
@@ -68,6 +69,8 @@ def lib():
         L.orc_transform.restype = None
         L.orc_crop.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p]
         L.orc_crop.restype = C.c_size_t
+        L.orc_radius_outlier_removal.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_radius_outlier_removal.restype = C.c_size_t
         L.orc_voxel_cells.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.c_void_p]
         L.orc_voxel_cells.restype = None
         L.orc_voxelgrid.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.c_uint32, C.c_int,
@@ -115,6 +118,16 @@ def crop(points, mn, mx):
     out = np.empty_like(points)
     k = lib().orc_crop(points.ctypes.data, len(points), _f3(mn), _f3(mx), out.ctypes.data)
     return out[:k].copy()
+
+
+def radius_outlier_removal(points, radius, min_neighbors=1):
+    """Returns (survivors, keep mask)."""
+    points = np.ascontiguousarray(points, dtype=POINT_DTYPE)
+    out = np.empty_like(points)
+    mask = np.zeros(len(points), dtype=np.uint8)
+    k = lib().orc_radius_outlier_removal(points.ctypes.data, len(points), float(radius), int(min_neighbors),
+                                         out.ctypes.data, mask.ctypes.data)
+    return out[:k].copy(), mask.astype(bool)
 
 
 def voxel_cells(points, leaf):
@@ -165,6 +178,10 @@ def merge_voxelize(sensors, params, threads=1, stable=False, want_merged=True):
     if params.crop_min is not None:
         p.crop_enable = 1
         p.crop_min, p.crop_max = _f3(params.crop_min), _f3(params.crop_max)
+    if getattr(params, "outlier_radius", None):
+        p.outlier_enable = 1
+        p.outlier_radius = float(params.outlier_radius)
+        p.outlier_min_neighbors = int(params.outlier_min_neighbors)
     merged = np.empty(max(n_in, 1), dtype=POINT_DTYPE) if want_merged else None
     out = np.empty(max(n_in, 1), dtype=POINT_DTYPE)
     rep = Report()
