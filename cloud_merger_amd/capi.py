@@ -46,7 +46,8 @@ class Params(C.Structure):
     _fields_ = [("leaf", C.c_float * 3), ("min_points_per_voxel", C.c_uint32),
                 ("downsample_all_data", C.c_int32), ("crop_enable", C.c_int32),
                 ("crop_min", C.c_float * 3), ("crop_max", C.c_float * 3),
-                ("required_sensor_mask", C.c_uint32), ("_reserved", C.c_uint32)]
+                ("required_sensor_mask", C.c_uint32), ("outlier_enable", C.c_int32),
+                ("outlier_radius", C.c_float), ("outlier_min_neighbors", C.c_uint32)]
 
 
 class Result(C.Structure):
@@ -137,6 +138,10 @@ def make_params(p: MergeParams) -> Params:
         cp.crop_min = (C.c_float * 3)(*[float(v) for v in p.crop_min])
         cp.crop_max = (C.c_float * 3)(*[float(v) for v in p.crop_max])
     cp.required_sensor_mask = int(p.required_sensor_mask)
+    if getattr(p, "outlier_radius", None):
+        cp.outlier_enable = 1
+        cp.outlier_radius = float(p.outlier_radius)
+        cp.outlier_min_neighbors = int(p.outlier_min_neighbors)
     return cp
 
 

@@ -60,6 +60,11 @@ struct cm_ctx {
     uint32_t *out_key = nullptr, *out_cnt = nullptr, *merged_total = nullptr;
     void* out = nullptr;
     void* merged = nullptr;
+    unsigned char* mask = nullptr;       // outlier stage: keep-mask over the padded point indices
+    void* sorted_pts = nullptr;          // outlier stage: points in radius-grid order
+    void* rows = nullptr;                // outlier stage: (y,z)-row ranges
+    CmFrameState* d_state_o = nullptr;   // outlier stage: its grid and counts
+    const unsigned char* frame_mask = nullptr;   // mask of the last frame (nullptr: stage off)
     void* partial = nullptr;             // cm_partial_entry table of the last cm_merge_partial
     void* table_entries = nullptr;       // merged entries inside cm_merge_tables
     int last_mode = 0;
@@ -175,7 +180,7 @@ void prof_mark(cm_ctx* c, const char* name) {
 void free_all(cm_ctx* c) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(c->keys_a); F(c->keys_b); F(c->vals_a); F(c->vals_b); F(c->hist); F(c->totals);
-    F(c->seg_counts); F(c->seg_tile_counts); F(c->seg_groups); F(c->grp); F(c->partials); F(c->out_key); F(c->out_cnt); F(c->merged_total); F(c->out); F(c->merged); F(c->partial); F(c->table_entries);
+    F(c->seg_counts); F(c->seg_tile_counts); F(c->seg_groups); F(c->grp); F(c->partials); F(c->out_key); F(c->out_cnt); F(c->merged_total); F(c->out); F(c->merged); F(c->partial); F(c->table_entries); F(c->mask); F(c->sorted_pts); F(c->rows); F(c->d_state_o);
     F(c->d_frame); F(c->d_state[0]); F(c->d_state[1]);
     if (c->h_state) (void)hipHostFree(c->h_state);
     for (auto& s : c->slots) {
@@ -304,6 +309,14 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
         return CM_OK;
     }
 
+    const bool outl = p->outlier_enable != 0;
+    if (outl && mode != 0) return fail(c, CM_BAD_ARG, "outlier removal needs the whole fused cloud on one GPU (not with partial tables)");
+    if (outl) {
+        if (!(p->outlier_radius > 0.0f) || !std::isfinite(p->outlier_radius)) return fail(c, CM_BAD_ARG, "outlier_radius must be > 0");
+        for (int a = 0; a < 3; ++a) f.inv_cell[a] = 1.0f / (p->outlier_radius * 1.01f);   // candidate grid a little wider than r
+        f.outlier_r2 = static_cast<float>(static_cast<double>(p->outlier_radius) * static_cast<double>(p->outlier_radius));
+        f.outlier_min_nb = p->outlier_min_neighbors;
+    }
     hipStream_t st = c->stream;
     if (!c->frame_uploaded_valid || std::memcmp(&f, &c->frame_uploaded, sizeof f) != 0) {
         prof_mark(c, "k_setup");
@@ -326,32 +339,64 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
     const uint32_t n_partials = nt < CM_MINMAX_BLOCKS ? nt : CM_MINMAX_BLOCKS;
     const uint32_t n_groups = (nt + CM_GROUP - 1) / CM_GROUP;
     const uint32_t gw = n_groups * CM_RADIX;                     // words of one group-total array
-    // grp: [0],[1] pass-0 arrays (alternate per frame: k_keys accumulates into one and clears the
-    // other for the next frame), [2..4] passes 1..3 (cleared by k_keys, filled by k_hist).
+    // grp: [0],[1] pass-0 arrays (alternate per k_keys launch: it accumulates into one and clears the
+    // other for the next launch), [2..4] passes 1..3 (cleared by k_keys, filled by k_hist).
     const size_t gstride = static_cast<size_t>(c->cap_groups) * CM_RADIX;
-    uint32_t* grp0 = c->grp + gstride * (c->frame_seq & 1u);
-    uint32_t* grp0_next = c->grp + gstride * ((c->frame_seq & 1u) ^ 1u);
-    ++c->frame_seq;
     const bool big = n_groups > CM_DIRECT_GROUPS;
-    if (!c->from_crop) { prof_mark(c, "k_minmax"); cmk_minmax(st, c->d_frame, c->partials, n_partials); }
-    prof_mark(c, "k_keys");
-    cmk_keys(st, c->d_frame, state, c->keys_a, c->hist, grp0, grp0_next, c->grp + 2 * gstride, gw,
-             static_cast<uint32_t>(gstride), c->seg_groups, (nseg + CM_SEG_GROUP - 1) / CM_SEG_GROUP + 1,
-             c->partials, n_partials, grid_mode, nt);
-    // NOTE: k_keys clears 3*gw words starting at grp[2]; passes 1..3 therefore live at stride gw.
-    for (uint32_t pass = 0; pass < passes; ++pass) {
-        const bool even = (pass & 1u) == 0;
-        const uint32_t* kin = even ? c->keys_a : c->keys_b;
-        const uint32_t* vin = even ? c->vals_a : c->vals_b;
-        uint32_t* kout = even ? c->keys_b : c->keys_a;
-        uint32_t* vout = even ? c->vals_b : c->vals_a;
-        uint32_t* grp = pass == 0 ? grp0 : c->grp + 2 * gstride + static_cast<size_t>(pass - 1) * gw;
-        if (pass > 0) { prof_mark(c, "k_hist"); cmk_hist(st, state, kin, c->hist, grp, pass, nt); }
-        if (big) { prof_mark(c, "k_gscan"); cmk_gscan(st, state, grp, c->totals, pass, n_groups); }
-        prof_mark(c, "k_scatter");
-        cmk_scatter(st, state, kin, vin, kout, vout, c->hist, grp, big ? c->totals : nullptr, pass, nt,
-                    n_groups, f.n_padded, c->lds_rank);
+    const uint32_t n_seg_groups = (nseg + CM_SEG_GROUP - 1) / CM_SEG_GROUP + 1;
+
+    // keys + radix sort of one stage (the voxel grid, or the outlier stage's radius grid)
+    auto keys_and_sort = [&](CmFrameState* stg, int gmode, int use_cell, const unsigned char* mask,
+                             const CmFrameState* st_outlier, uint32_t n_pass) {
+        uint32_t* grp0 = c->grp + gstride * (c->frame_seq & 1u);
+        uint32_t* grp0_next = c->grp + gstride * ((c->frame_seq & 1u) ^ 1u);
+        ++c->frame_seq;
+        prof_mark(c, use_cell ? "k_keys(outlier)" : "k_keys");
+        cmk_keys(st, c->d_frame, stg, c->keys_a, c->hist, grp0, grp0_next, c->grp + 2 * gstride, gw,
+                 static_cast<uint32_t>(gstride), c->seg_groups, n_seg_groups, c->partials, n_partials, gmode,
+                 use_cell, mask, st_outlier, nt);
+        // k_keys clears 3*gw words starting at grp[2]; passes 1..3 therefore live at stride gw.
+        for (uint32_t pass = 0; pass < n_pass; ++pass) {
+            const bool even = (pass & 1u) == 0;
+            const uint32_t* kin = even ? c->keys_a : c->keys_b;
+            const uint32_t* vin = even ? c->vals_a : c->vals_b;
+            uint32_t* kout = even ? c->keys_b : c->keys_a;
+            uint32_t* vout = even ? c->vals_b : c->vals_a;
+            uint32_t* grp = pass == 0 ? grp0 : c->grp + 2 * gstride + static_cast<size_t>(pass - 1) * gw;
+            if (pass > 0) { prof_mark(c, "k_hist"); cmk_hist(st, stg, kin, c->hist, grp, pass, nt); }
+            if (big) { prof_mark(c, "k_gscan"); cmk_gscan(st, stg, grp, c->totals, pass, n_groups); }
+            prof_mark(c, "k_scatter");
+            cmk_scatter(st, stg, kin, vin, kout, vout, c->hist, grp, big ? c->totals : nullptr, pass, nt,
+                        n_groups, f.n_padded, c->lds_rank);
+        }
+    };
+
+    c->frame_mask = nullptr;
+    if (outl) {
+        // Radius outlier removal first: it decides which points the voxel grid sees at all.
+        if (!c->mask) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->mask), c->cap_padded));
+        if (!c->sorted_pts) HIP_TRY(c, hipMalloc(&c->sorted_pts, static_cast<size_t>(c->cap_padded) * 16));
+        if (!c->rows) HIP_TRY(c, hipMalloc(&c->rows, static_cast<size_t>(CM_ROW_TABLE_CAP) * 8));
+        if (!c->d_state_o) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_state_o), sizeof(CmFrameState)));
+        uint32_t kb_o = 0;
+        int gm_o = 0;
+        if (f.crop_enable) {
+            if (!box_grid(p->crop_min, p->crop_max, f.inv_cell, &kb_o))
+                return fail(c, CM_CAPACITY, "outlier radius too small for the crop box (radius grid exceeds 32 bits)");
+            gm_o = 1;
+        }
+        const uint32_t passes_o = gm_o ? (kb_o + CM_RADIX_BITS - 1) / CM_RADIX_BITS : CM_MAX_PASSES;
+        HIP_TRY(c, hipMemsetAsync(c->d_state_o, 0, sizeof(CmFrameState), st));
+        HIP_TRY(c, hipMemsetAsync(c->mask, 0, f.n_padded, st));
+        if (!gm_o) { prof_mark(c, "k_minmax"); cmk_minmax(st, c->d_frame, c->partials, n_partials, nullptr); }
+        keys_and_sort(c->d_state_o, gm_o, 1, nullptr, nullptr, passes_o);
+        prof_mark(c, "outlier_mask");
+        cmk_outlier_mask(st, c->d_frame, c->d_state_o, c->keys_a, c->vals_a, c->keys_b, c->vals_b, c->sorted_pts,
+                         c->rows, c->mask, f.n_padded);
+        c->frame_mask = c->mask;
     }
+    if (!c->from_crop) { prof_mark(c, "k_minmax"); cmk_minmax(st, c->d_frame, c->partials, n_partials, c->frame_mask); }
+    keys_and_sort(state, grid_mode, 0, c->frame_mask, outl ? c->d_state_o : nullptr, passes);
     prof_mark(c, "k_seg_count");
     uint32_t* seg_groups = nseg > CM_SEG_DIRECT_TILES ? c->seg_groups : nullptr;
     cmk_seg_count(st, state, c->keys_a, c->keys_b, c->seg_tile_counts, seg_groups, mode == 1 ? 1u : f.min_pts, nseg);
@@ -394,6 +439,10 @@ int wait_frame(cm_ctx* c, cm_result* res) {
             }
             return fail(c, CM_INTERNAL, "device reported an internal error");
         }
+        if (h.status == CM_DEV_OUTLIER_GRID) {
+            c->pending = false;
+            return fail(c, CM_CAPACITY, "outlier radius too small for the cloud's extent (radius grid exceeds its limits)");
+        }
         r.status = h.status;
         r.bounds_from_crop = c->from_crop ? 1u : 0u;
         for (int a = 0; a < 3; ++a) {
@@ -408,7 +457,7 @@ int wait_frame(cm_ctx* c, cm_result* res) {
             r.n_out = h.n_out;
         } else if (h.status == CM_GRID_OVERFLOW) {
             // PCL: "output = *input_" — hand back the merged cloud, unvoxelised (A.4 step 3).
-            cmk_merged(c->stream, c->d_frame, c->seg_counts, c->merged_total, c->out, c->frame.n_tiles);
+            cmk_merged(c->stream, c->d_frame, c->seg_counts, c->merged_total, c->out, c->frame.n_tiles, c->frame_mask);
             uint32_t total = 0;
             HIP_TRY(c, hipMemcpyAsync(&total, c->merged_total, 4, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -695,7 +744,7 @@ int cm_merged_copy(cm_ctx* c, void* host_dst, uint64_t capacity, uint64_t* n_poi
     if (!c->merged) HIP_TRY(c, hipMalloc(&c->merged, static_cast<size_t>(c->cap_padded) * 16));
     // seg_counts holds this frame's output offsets in its first cap_seg_tiles words; use the tail.
     uint32_t* counts = c->seg_counts + c->cap_seg_tiles;
-    cmk_merged(c->stream, c->d_frame, counts, c->merged_total, c->merged, c->frame.n_tiles);
+    cmk_merged(c->stream, c->d_frame, counts, c->merged_total, c->merged, c->frame.n_tiles, c->frame_mask);
     uint32_t total = 0;
     HIP_TRY(c, hipMemcpyAsync(&total, c->merged_total, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -727,7 +776,7 @@ int cm_local_bounds(cm_ctx* c, const cm_params* p, float min_xyz[3], float max_x
     c->frame_uploaded = f;
     c->frame_uploaded_valid = true;
     const uint32_t n_partials = f.n_tiles < CM_MINMAX_BLOCKS ? f.n_tiles : CM_MINMAX_BLOCKS;
-    cmk_minmax(c->stream, c->d_frame, c->partials, n_partials);
+    cmk_minmax(c->stream, c->d_frame, c->partials, n_partials, nullptr);
     std::vector<float> rec(static_cast<size_t>(n_partials) * 8);
     HIP_TRY(c, hipMemcpyAsync(rec.data(), c->partials, rec.size() * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

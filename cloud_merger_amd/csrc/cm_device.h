@@ -51,6 +51,9 @@ struct CmFrameDev {
     float inv_leaf[3];        // 1.0f / leaf, computed once on the host in fp32
     uint32_t min_pts;
     uint32_t downsample_all;
+    float inv_cell[3];        // outlier stage: 1 / (1.01 * radius) — candidate grid a little wider than the radius
+    float outlier_r2;         // float(double(r) * double(r)): FLANN compares squared distances
+    uint32_t outlier_min_nb;
     float ext_min[3];         // grid bounds handed in by the host (fused cloud across GPUs: the
     float ext_max[3];         // min/max of the WHOLE merged cloud, all-reduced over the ranks)
 };
@@ -74,3 +77,6 @@ struct CmFrameState {
 #define CM_DEV_OK 0
 #define CM_DEV_EMPTY 1
 #define CM_DEV_OVERFLOW 2
+#define CM_DEV_OUTLIER_GRID 3   // the radius grid of the outlier stage does not fit (rows or 32-bit index)
+
+#define CM_ROW_TABLE_CAP (1u << 22)   // rows (y,z cell pairs) of the outlier stage's candidate grid

@@ -6,11 +6,16 @@
 #include "cm_device.h"
 
 void cmk_setup(hipStream_t s, const CmFrameDev& f, CmFrameDev* d_frame);
-void cmk_minmax(hipStream_t s, const CmFrameDev* fd, float* partials, uint32_t n_blocks);
+void cmk_minmax(hipStream_t s, const CmFrameDev* fd, float* partials, uint32_t n_blocks, const unsigned char* mask);
 void cmk_keys(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* keys, uint32_t* hist,
               uint32_t* grp_acc, uint32_t* grp_clear_a, uint32_t* grp_clear_b, uint32_t n_group_words,
               uint32_t n_clear_a_words, uint32_t* seg_groups, uint32_t n_seg_groups, const float* partials,
-              uint32_t n_partials, int from_crop, uint32_t n_tiles);
+              uint32_t n_partials, int from_crop, int use_cell, const unsigned char* mask,
+              const CmFrameState* st_outlier, uint32_t n_tiles);
+// Outlier stage after the sort by the radius grid: gather into sorted order, row table, neighbour counts -> mask.
+void cmk_outlier_mask(hipStream_t s, const CmFrameDev* fd, const CmFrameState* st, const uint32_t* keys_a,
+                      const uint32_t* vals_a, const uint32_t* keys_b, const uint32_t* vals_b, void* sorted_pts,
+                      void* rows, unsigned char* mask, uint32_t n_padded);
 void cmk_hist(hipStream_t s, const CmFrameState* st, const uint32_t* keys, uint32_t* hist, uint32_t* grp,
               uint32_t pass, uint32_t n_tiles);
 void cmk_gscan(hipStream_t s, const CmFrameState* st, uint32_t* grp, uint32_t* totals, uint32_t pass,
@@ -35,4 +40,4 @@ void cmk_table_keys(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint3
 void cmk_table_finish(hipStream_t s, const void* entries, uint32_t n, uint32_t min_pts, uint32_t* tile_counts,
                       uint32_t* total, void* out, uint32_t* out_key, uint32_t* out_cnt);
 void cmk_merged(hipStream_t s, const CmFrameDev* fd, uint32_t* tile_counts, uint32_t* total, void* out,
-                uint32_t n_tiles);
+                uint32_t n_tiles, const unsigned char* mask);

@@ -164,7 +164,8 @@ __device__ __forceinline__ void load_tile(const CmSensorDev& sd, uint32_t first,
 // workgroup (min xyz, max xyz, valid count), no atomics; k_keys folds the records.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(CM_BLOCK) void k_minmax(const CmFrameDev* __restrict__ fd,
-                                                     float* __restrict__ partials) {
+                                                     float* __restrict__ partials,
+                                                     const unsigned char* __restrict__ mask) {
     __shared__ float s_red[CM_WAVES][6];
     __shared__ uint32_t s_cnt[CM_WAVES];
     const uint32_t crop = fd->crop_enable;
@@ -178,7 +179,8 @@ __global__ __launch_bounds__(CM_BLOCK) void k_minmax(const CmFrameDev* __restric
         float m[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) m[k] = sd.m[k];
-        const uint32_t first = tile * CM_TILE - sd.base + w * (64 * CM_ITEMS) + lane;
+        const uint32_t slot0 = tile * CM_TILE + w * (64 * CM_ITEMS) + lane;
+        const uint32_t first = slot0 - sd.base;
         Pt p[CM_ITEMS];
         load_tile(sd, first, p);
 #pragma unroll
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_minmax(const CmFrameDev* __restric
             const float x = xf_row(m[0], m[1], m[2], m[3], p[r].x, p[r].y, p[r].z);
             const float y = xf_row(m[4], m[5], m[6], m[7], p[r].x, p[r].y, p[r].z);
             const float z = xf_row(m[8], m[9], m[10], m[11], p[r].x, p[r].y, p[r].z);
-            if (point_valid(x, y, z, crop, fd->crop_min, fd->crop_max)) {
+            if (point_valid(x, y, z, crop, fd->crop_min, fd->crop_max) && (!mask || mask[slot0 + r * 64])) {
                 mn0 = fminf(mn0, x); mx0 = fmaxf(mx0, x);
                 mn1 = fminf(mn1, y); mx1 = fmaxf(mx1, y);
                 mn2 = fminf(mn2, z); mx2 = fmaxf(mx2, z);
@@ -234,7 +236,7 @@ struct Grid {
 
 __device__ __forceinline__ void compute_grid(const CmFrameDev* __restrict__ fd,
                                              const float* __restrict__ partials, uint32_t n_partials,
-                                             int from_crop, float (*s_red)[8], Grid& g) {
+                                             int from_crop, const float* __restrict__ inv, float (*s_red)[8], Grid& g) {
     g.status = CM_DEV_OK;
     g.key_bits = 0; g.n_passes = 0; g.n_valid_k0 = 0;
 #pragma unroll
@@ -291,7 +293,7 @@ __device__ __forceinline__ void compute_grid(const CmFrameDev* __restrict__ fd,
     bool overflow = false;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const float ext = __fmul_rn(__fsub_rn(g.max_p[a], g.min_p[a]), fd->inv_leaf[a]);
+        const float ext = __fmul_rn(__fsub_rn(g.max_p[a], g.min_p[a]), inv[a]);
         if (!(ext < 2147483648.0f)) { overflow = true; d[a] = 0; }
         else d[a] = static_cast<long long>(ext) + 1;       // truncation toward zero
     }
@@ -300,8 +302,8 @@ __device__ __forceinline__ void compute_grid(const CmFrameDev* __restrict__ fd,
     unsigned long long cells = 1;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const int lo = static_cast<int>(floorf(__fmul_rn(g.min_p[a], fd->inv_leaf[a])));
-        const int hi = static_cast<int>(floorf(__fmul_rn(g.max_p[a], fd->inv_leaf[a])));
+        const int lo = static_cast<int>(floorf(__fmul_rn(g.min_p[a], inv[a])));
+        const int hi = static_cast<int>(floorf(__fmul_rn(g.max_p[a], inv[a])));
         g.min_b[a] = lo; g.max_b[a] = hi; g.div_b[a] = hi - lo + 1;
         cells *= static_cast<unsigned long long>(hi - lo + 1);
     }
@@ -329,10 +331,13 @@ __global__ __launch_bounds__(CM_BLOCK) void k_keys(const CmFrameDev* __restrict_
                                                    uint32_t n_group_words, uint32_t n_clear_a_words,
                                                    uint32_t* __restrict__ seg_groups, uint32_t n_seg_groups,
                                                    const float* __restrict__ partials,
-                                                   uint32_t n_partials, int from_crop) {
+                                                   uint32_t n_partials, int from_crop, int use_cell,
+                                                   const unsigned char* __restrict__ mask,
+                                                   const CmFrameState* __restrict__ st_outlier) {
     __shared__ uint32_t lh[CM_RADIX];
     __shared__ float s_red[CM_WAVES][8];
     const uint32_t tile = blockIdx.x;
+    const float* __restrict__ inv = use_cell ? fd->inv_cell : fd->inv_leaf;
     // kept-voxel totals per group of sorted tiles (k_seg_count accumulates into them)
     for (uint32_t k = tile * CM_BLOCK + threadIdx.x; k < n_seg_groups * 32; k += gridDim.x * CM_BLOCK) seg_groups[k] = 0;
     // Clear the group totals of passes 1..3 (grp_clear_b, three arrays) and the pass-0 array the
@@ -344,7 +349,12 @@ __global__ __launch_bounds__(CM_BLOCK) void k_keys(const CmFrameDev* __restrict_
         grp_clear_a[k] = 0;                             // whole array: the next frame may be larger
 
     Grid g;
-    compute_grid(fd, partials, n_partials, from_crop, s_red, g);
+    compute_grid(fd, partials, n_partials, from_crop, inv, s_red, g);
+    if (use_cell && g.status == CM_DEV_OVERFLOW) g.status = CM_DEV_OUTLIER_GRID;
+    if (use_cell && g.status == CM_DEV_OK &&
+        static_cast<unsigned long long>(g.div_b[1]) * static_cast<unsigned long long>(g.div_b[2]) > CM_ROW_TABLE_CAP)
+        g.status = CM_DEV_OUTLIER_GRID;
+    if (st_outlier && st_outlier->status == CM_DEV_OUTLIER_GRID) g.status = CM_DEV_OUTLIER_GRID;
     if (tile == 0 && threadIdx.x == 0) {
         st->status = g.status;
         st->n_valid_k0 = g.n_valid_k0;
@@ -363,7 +373,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_keys(const CmFrameDev* __restrict_
 #pragma unroll
     for (int k = 0; k < 12; ++k) m[k] = sd.m[k];
     const uint32_t crop = fd->crop_enable;
-    const float inv0 = fd->inv_leaf[0], inv1 = fd->inv_leaf[1], inv2 = fd->inv_leaf[2];
+    const float inv0 = inv[0], inv1 = inv[1], inv2 = inv[2];
     const float fb0 = static_cast<float>(g.min_b[0]), fb1 = static_cast<float>(g.min_b[1]),
                 fb2 = static_cast<float>(g.min_b[2]);
     const uint32_t mul1 = static_cast<uint32_t>(g.div_b[0]);
@@ -382,7 +392,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_keys(const CmFrameDev* __restrict_
         const float x = xf_row(m[0], m[1], m[2], m[3], p[r].x, p[r].y, p[r].z);
         const float y = xf_row(m[4], m[5], m[6], m[7], p[r].x, p[r].y, p[r].z);
         const float z = xf_row(m[8], m[9], m[10], m[11], p[r].x, p[r].y, p[r].z);
-        if (point_valid(x, y, z, crop, fd->crop_min, fd->crop_max)) {
+        if (point_valid(x, y, z, crop, fd->crop_min, fd->crop_max) && (!mask || mask[slot0 + r * 64])) {
             const int c0 = static_cast<int>(__fsub_rn(floorf(__fmul_rn(x, inv0)), fb0));
             const int c1 = static_cast<int>(__fsub_rn(floorf(__fmul_rn(y, inv1)), fb1));
             const int c2 = static_cast<int>(__fsub_rn(floorf(__fmul_rn(z, inv2)), fb2));
@@ -1130,12 +1140,123 @@ __global__ __launch_bounds__(CM_BLOCK) void k_table_finish(const float4* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// Radius outlier removal on the fused cloud (reference remove_outliers,
+// my_cloud_fusion/src/CloudFusionNode.h:74-85, applied before voxelgrid at cloud_fusion_node.cpp:72;
+// live node outlierRemoval pc_preprocessing_main.cpp:184-192). pcl::RadiusOutlierRemoval keeps a
+// point iff k > min_neighbors, k = points (itself included) with fp32 squared distance
+// ((dx*dx + dy*dy) + dz*dz) < float(r*r).
+// Candidates come from a grid a little wider than the radius: the fused cloud is sorted by that
+// grid's linear cell index with the same radix sort, the points are gathered once into sorted
+// order (so the cells of a row are contiguous), a (y,z)-row table gives each row's range, and one
+// thread per point walks the 9 neighbouring rows x 3 cells, stopping at min_neighbors + 1 hits.
+// The result is a keep-mask over the padded point indices that k_minmax / k_keys honour.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(CM_BLOCK) void k_gather_sorted(const CmFrameDev* __restrict__ fd,
+                                                            const CmFrameState* __restrict__ st,
+                                                            const uint32_t* __restrict__ vals_a,
+                                                            const uint32_t* __restrict__ vals_b,
+                                                            float4* __restrict__ sorted_pts) {
+    __shared__ SensorLds tab[CM_DEV_MAX_SENSORS];
+    const uint32_t n_sensors = fd->n_sensors;
+    if (threadIdx.x < n_sensors) {
+        const CmSensorDev& g = fd->s[threadIdx.x];
+        SensorLds& t = tab[threadIdx.x];
+        t.data = g.data; t.base = g.base; t.step = g.point_step;
+        t.ox = g.off_x; t.oy = g.off_y; t.oz = g.off_z; t.oi = g.off_i; t.layout = g.layout;
+        for (int k = 0; k < 12; ++k) t.m[k] = g.m[k];
+    }
+    __syncthreads();
+    if (st->status != CM_DEV_OK) return;
+    const uint32_t n = st->n_valid;
+    const uint32_t* __restrict__ vals = pick(st, vals_a, vals_b);
+    for (uint32_t p = blockIdx.x * CM_BLOCK + threadIdx.x; p < n; p += gridDim.x * CM_BLOCK) {
+        const uint32_t idx = vals[p];
+        const Acc a = gather_item<SEG_PARTIAL>(tab, n_sensors, idx, false);
+        sorted_pts[p] = make_float4(a.x, a.y, a.z, __uint_as_float(idx));
+    }
+}
+
+__global__ __launch_bounds__(CM_BLOCK) void k_row_clear(const CmFrameState* __restrict__ st, uint2* __restrict__ rows) {
+    if (st->status != CM_DEV_OK) return;
+    const uint32_t n_rows = static_cast<uint32_t>(st->div_b[1]) * static_cast<uint32_t>(st->div_b[2]);
+    for (uint32_t r = blockIdx.x * CM_BLOCK + threadIdx.x; r < n_rows; r += gridDim.x * CM_BLOCK) rows[r] = make_uint2(0u, 0u);
+}
+
+__global__ __launch_bounds__(CM_BLOCK) void k_row_table(const CmFrameState* __restrict__ st,
+                                                        const uint32_t* __restrict__ keys_a,
+                                                        const uint32_t* __restrict__ keys_b,
+                                                        uint2* __restrict__ rows) {
+    if (st->status != CM_DEV_OK) return;
+    const uint32_t n = st->n_valid;
+    const uint32_t dx = static_cast<uint32_t>(st->div_b[0]);
+    const uint32_t* __restrict__ keys = pick(st, keys_a, keys_b);
+    for (uint32_t p = blockIdx.x * CM_BLOCK + threadIdx.x; p < n; p += gridDim.x * CM_BLOCK) {
+        const uint32_t row = keys[p] / dx;
+        const uint32_t prev = p ? keys[p - 1] / dx : 0xFFFFFFFFu;
+        if (row != prev) {
+            rows[row].x = p;
+            if (p) rows[prev].y = p;
+        }
+        if (p == n - 1) rows[row].y = n;
+    }
+}
+
+__global__ __launch_bounds__(CM_BLOCK) void k_neighbors(const CmFrameDev* __restrict__ fd,
+                                                        const CmFrameState* __restrict__ st,
+                                                        const uint32_t* __restrict__ keys_a,
+                                                        const uint32_t* __restrict__ keys_b,
+                                                        const float4* __restrict__ sorted_pts,
+                                                        const uint2* __restrict__ rows,
+                                                        unsigned char* __restrict__ mask) {
+    if (st->status != CM_DEV_OK) return;
+    const uint32_t n = st->n_valid;
+    const uint32_t dx = static_cast<uint32_t>(st->div_b[0]), dy = static_cast<uint32_t>(st->div_b[1]),
+                   dz = static_cast<uint32_t>(st->div_b[2]);
+    const uint32_t* __restrict__ keys = pick(st, keys_a, keys_b);
+    const float r2 = fd->outlier_r2;
+    const uint32_t need = fd->outlier_min_nb;            // keep iff k > need, k counts the point itself
+    for (uint32_t p = blockIdx.x * CM_BLOCK + threadIdx.x; p < n; p += gridDim.x * CM_BLOCK) {
+        const uint32_t key = keys[p];
+        const float4 me = sorted_pts[p];
+        const uint32_t i = key % dx, jk = key / dx, j = jk % dy, k = jk / dy;
+        const uint32_t i_lo = i ? i - 1 : 0u, i_hi = (i + 1 < dx) ? i + 1 : dx - 1;
+        uint32_t cnt = 0;
+        for (int dk = -1; dk <= 1 && cnt <= need; ++dk) {
+            const int kk = static_cast<int>(k) + dk;
+            if (kk < 0 || kk >= static_cast<int>(dz)) continue;
+            for (int dj = -1; dj <= 1 && cnt <= need; ++dj) {
+                const int jj = static_cast<int>(j) + dj;
+                if (jj < 0 || jj >= static_cast<int>(dy)) continue;
+                const uint32_t row = static_cast<uint32_t>(jj) + static_cast<uint32_t>(kk) * dy;
+                const uint2 range = rows[row];
+                if (range.x >= range.y) continue;
+                const uint32_t lo_key = row * dx + i_lo, hi_key = row * dx + i_hi;
+                uint32_t a = range.x, b = range.y;           // first position with key >= lo_key
+                while (a < b) {
+                    const uint32_t mid = (a + b) >> 1;
+                    if (keys[mid] < lo_key) a = mid + 1; else b = mid;
+                }
+                for (uint32_t q = a; q < range.y && cnt <= need; ++q) {
+                    if (keys[q] > hi_key) break;
+                    const float4 o = sorted_pts[q];
+                    const float ex = __fsub_rn(me.x, o.x), ey = __fsub_rn(me.y, o.y), ez = __fsub_rn(me.z, o.z);
+                    const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez));
+                    if (d2 < r2) ++cnt;
+                }
+            }
+        }
+        if (cnt > need) mask[__float_as_uint(me.w)] = 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Merged-cloud materialisation (the reference's fused cloud, :137-142): stable compaction of the
 // valid transformed points into 16-byte records. Used for CM_GRID_OVERFLOW (output = input) and
 // by parity tests; not on the timed path.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(CM_BLOCK) void k_merged_count(const CmFrameDev* __restrict__ fd,
-                                                           uint32_t* __restrict__ tile_counts) {
+                                                           uint32_t* __restrict__ tile_counts,
+                                                           const unsigned char* __restrict__ mask) {
     __shared__ uint32_t lds[CM_WAVES];
     const uint32_t tile = blockIdx.x;
     const uint32_t s = sensor_of_tile(fd, tile);
@@ -1149,7 +1270,8 @@ __global__ __launch_bounds__(CM_BLOCK) void k_merged_count(const CmFrameDev* __r
             const float x = xf_row(sd.m[0], sd.m[1], sd.m[2], sd.m[3], p.x, p.y, p.z);
             const float y = xf_row(sd.m[4], sd.m[5], sd.m[6], sd.m[7], p.x, p.y, p.z);
             const float z = xf_row(sd.m[8], sd.m[9], sd.m[10], sd.m[11], p.x, p.y, p.z);
-            cnt += point_valid(x, y, z, fd->crop_enable, fd->crop_min, fd->crop_max) ? 1u : 0u;
+            cnt += (point_valid(x, y, z, fd->crop_enable, fd->crop_min, fd->crop_max) &&
+                    (!mask || mask[tile * CM_TILE + r * CM_BLOCK + threadIdx.x])) ? 1u : 0u;
         }
     }
     const uint32_t tot = block_sum_u32(cnt, lds);
@@ -1173,7 +1295,8 @@ __global__ __launch_bounds__(CM_BLOCK) void k_scan_counts(uint32_t* __restrict__
 
 __global__ __launch_bounds__(CM_BLOCK) void k_merged_write(const CmFrameDev* __restrict__ fd,
                                                            const uint32_t* __restrict__ tile_offs,
-                                                           float4* __restrict__ out) {
+                                                           float4* __restrict__ out,
+                                                           const unsigned char* __restrict__ mask) {
     __shared__ uint32_t lds[CM_WAVES];
     const uint32_t tile = blockIdx.x;
     const uint32_t s = sensor_of_tile(fd, tile);
@@ -1190,7 +1313,8 @@ __global__ __launch_bounds__(CM_BLOCK) void k_merged_write(const CmFrameDev* __r
             o.y = xf_row(sd.m[4], sd.m[5], sd.m[6], sd.m[7], p.x, p.y, p.z);
             o.z = xf_row(sd.m[8], sd.m[9], sd.m[10], sd.m[11], p.x, p.y, p.z);
             o.w = p.i;
-            ok = point_valid(o.x, o.y, o.z, fd->crop_enable, fd->crop_min, fd->crop_max);
+            ok = point_valid(o.x, o.y, o.z, fd->crop_enable, fd->crop_min, fd->crop_max) &&
+                 (!mask || mask[tile * CM_TILE + r * CM_BLOCK + threadIdx.x]);
         }
         uint32_t tot;
         const uint32_t ex = block_excl_scan_u32(ok ? 1u : 0u, lds, &tot);
@@ -1210,15 +1334,27 @@ __global__ __launch_bounds__(CM_BLOCK) void k_merged_write(const CmFrameDev* __r
 void cmk_setup(hipStream_t s, const CmFrameDev& f, CmFrameDev* d_frame) {
     CM_LAUNCH(k_setup, 1, 64, s, f, d_frame);
 }
-void cmk_minmax(hipStream_t s, const CmFrameDev* fd, float* partials, uint32_t n_blocks) {
-    CM_LAUNCH(k_minmax, n_blocks, CM_BLOCK, s, fd, partials);
+void cmk_minmax(hipStream_t s, const CmFrameDev* fd, float* partials, uint32_t n_blocks, const unsigned char* mask) {
+    CM_LAUNCH(k_minmax, n_blocks, CM_BLOCK, s, fd, partials, mask);
 }
 void cmk_keys(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* keys, uint32_t* hist,
               uint32_t* grp_acc, uint32_t* grp_clear_a, uint32_t* grp_clear_b, uint32_t n_group_words,
               uint32_t n_clear_a_words, uint32_t* seg_groups, uint32_t n_seg_groups, const float* partials,
-              uint32_t n_partials, int from_crop, uint32_t n_tiles) {
+              uint32_t n_partials, int from_crop, int use_cell, const unsigned char* mask,
+              const CmFrameState* st_outlier, uint32_t n_tiles) {
     CM_LAUNCH(k_keys, n_tiles, CM_BLOCK, s, fd, st, keys, hist, grp_acc, grp_clear_a, grp_clear_b,
-              n_group_words, n_clear_a_words, seg_groups, n_seg_groups, partials, n_partials, from_crop);
+              n_group_words, n_clear_a_words, seg_groups, n_seg_groups, partials, n_partials, from_crop,
+              use_cell, mask, st_outlier);
+}
+void cmk_outlier_mask(hipStream_t s, const CmFrameDev* fd, const CmFrameState* st, const uint32_t* keys_a,
+                      const uint32_t* vals_a, const uint32_t* keys_b, const uint32_t* vals_b, void* sorted_pts,
+                      void* rows, unsigned char* mask, uint32_t n_padded) {
+    const uint32_t blocks = (n_padded + CM_BLOCK * 4 - 1) / (CM_BLOCK * 4);
+    CM_LAUNCH(k_gather_sorted, blocks, CM_BLOCK, s, fd, st, vals_a, vals_b, reinterpret_cast<float4*>(sorted_pts));
+    CM_LAUNCH(k_row_clear, 1024, CM_BLOCK, s, st, reinterpret_cast<uint2*>(rows));
+    CM_LAUNCH(k_row_table, blocks, CM_BLOCK, s, st, keys_a, keys_b, reinterpret_cast<uint2*>(rows));
+    CM_LAUNCH(k_neighbors, (n_padded + CM_BLOCK - 1) / CM_BLOCK, CM_BLOCK, s, fd, st, keys_a, keys_b,
+              reinterpret_cast<const float4*>(sorted_pts), reinterpret_cast<const uint2*>(rows), mask);
 }
 void cmk_hist(hipStream_t s, const CmFrameState* st, const uint32_t* keys, uint32_t* hist, uint32_t* grp,
               uint32_t pass, uint32_t n_tiles) {
@@ -1288,8 +1424,8 @@ void cmk_table_finish(hipStream_t s, const void* entries, uint32_t n, uint32_t m
     CM_LAUNCH(k_table_finish, nt, CM_BLOCK, s, e, n, min_pts, tile_counts, reinterpret_cast<float4*>(out), out_key, out_cnt, 1);
 }
 void cmk_merged(hipStream_t s, const CmFrameDev* fd, uint32_t* tile_counts, uint32_t* total, void* out,
-                uint32_t n_tiles) {
-    CM_LAUNCH(k_merged_count, n_tiles, CM_BLOCK, s, fd, tile_counts);
+                uint32_t n_tiles, const unsigned char* mask) {
+    CM_LAUNCH(k_merged_count, n_tiles, CM_BLOCK, s, fd, tile_counts, mask);
     CM_LAUNCH(k_scan_counts, 1, CM_BLOCK, s, tile_counts, n_tiles, total);
-    CM_LAUNCH(k_merged_write, n_tiles, CM_BLOCK, s, fd, tile_counts, reinterpret_cast<float4*>(out));
+    CM_LAUNCH(k_merged_write, n_tiles, CM_BLOCK, s, fd, tile_counts, reinterpret_cast<float4*>(out), mask);
 }

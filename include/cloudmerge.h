@@ -45,7 +45,7 @@ typedef enum cm_status {
     CM_BAD_ARG = -1,
     CM_HIP_ERROR = -2,
     CM_NO_DEVICE = -3,
-    CM_CAPACITY = -4,      /* more points than cm_limits allows */
+    CM_CAPACITY = -4,      /* more points than cm_limits allows, or the outlier stage's radius grid does not fit */
     CM_INTERNAL = -5
 } cm_status;
 
@@ -72,7 +72,13 @@ typedef struct cm_params {
     float crop_min[3];             /* x,y,z closed interval; Parameter.h:31-35 */
     float crop_max[3];
     uint32_t required_sensor_mask; /* bit s: sensor s must be fresh (:134); 0 = all submitted */
-    uint32_t _reserved;
+    /* pcl::RadiusOutlierRemoval on the fused cloud before VoxelGrid (my_cloud_fusion/src/
+     * CloudFusionNode.h:74-85, called at cloud_fusion_node.cpp:72; live node outlierRemoval :184-192;
+     * SURVEY.md §8f rank 2). A point stays iff more than outlier_min_neighbors points (itself
+     * included) lie within outlier_radius (fp32 squared distance < float(r*r)). */
+    int32_t outlier_enable;
+    float outlier_radius;          /* setRadiusSearch; Parameter.h:23 (0.15), my_cloud_fusion Parameter.h:15 (0.1) */
+    uint32_t outlier_min_neighbors;/* setMinNeighborsInRadius; Parameter.h:24 (1) */
 } cm_params;
 
 typedef struct cm_result {

@@ -373,3 +373,43 @@ def test_both_ranking_variants(force):
     r = subprocess.run([sys.executable, "-c", _BALLOT_SCRIPT, root], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.strip().endswith("flags " + force)
+
+
+# ---- radius outlier removal on the fused cloud -------------------------
+@pytest.mark.parametrize("radius,min_nb", [(0.15, 1), (0.1, 1), (0.3, 3)])
+def test_outlier_removal_no_crop(radius, min_nb):
+    sensors, params = synth.config2(n_per_sensor=60_000, min_pts=2)
+    params.outlier_radius, params.outlier_min_neighbors = radius, min_nb
+    g, rep = check_against_oracle(sensors, params, exact_small_runs=True)
+    assert 0 < g["res"].n_merged < g["res"].n_in          # some points really are outliers
+
+
+def test_outlier_removal_reference_parameters():
+    """The class-based reference node's chain: ROI crop, outlier removal (r from Parameter.h), VoxelGrid."""
+    sensors, _ = synth.config3(n_per_sensor=200_000, n_sensors=6)
+    params = MergeParams(crop_min=(-15.0, -5.0, -0.5), crop_max=(60.0, 5.0, 3.0), outlier_radius=0.15,
+                         outlier_min_neighbors=1)
+    g, rep = check_against_oracle(sensors, params)
+    assert g["res"].bounds_from_crop == 1 and 0 < g["res"].n_merged
+
+
+def test_outlier_removal_small_known_case():
+    xyz = np.array([[0, 0, 0], [0.1, 0, 0], [5, 0, 0], [9, 9, 9], [9.05, 9, 9], [np.nan, 0, 0]], np.float32)
+    s = [xyzi_cloud(xyz, np.arange(6, dtype=np.float32), is_dense=False)]
+    p = MergeParams(leaf=(0.01,) * 3, min_points_per_voxel=0, outlier_radius=0.15, outlier_min_neighbors=1,
+                    crop_min=(-20, -20, -20), crop_max=(20, 20, 20))
+    g, rep = check_against_oracle(s, p)
+    assert sorted(g["merged"][:, 3].tolist()) == [0.0, 1.0, 3.0, 4.0]
+
+
+def test_outlier_radius_too_small_is_an_error():
+    sensors, params = synth.config2(n_per_sensor=5_000)
+    params.outlier_radius = 1e-5
+    with capi.CloudMerger(max_points_total=20_000, max_sensors=4) as cm:
+        cm.submit_all(sensors)
+        with pytest.raises(capi.CloudMergeError) as e:
+            cm.merge_voxelize(params)
+        assert e.value.status == capi.CAPACITY
+        params.outlier_radius = None                      # the context stays usable
+        cm.submit_all(sensors)
+        assert cm.merge_voxelize(params).status == capi.OK
