@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--min-pts", type=int, default=2, help="min points per voxel (reference: 2, PCL default: 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-frames", type=int, default=20)
+    ap.add_argument("--outlier-radius", type=float, default=0.0,
+                    help="also run pcl::RadiusOutlierRemoval (min 1 neighbour) on the fused cloud before VoxelGrid "
+                         "(SURVEY 8f rank 2; off for the headline metric)")
     ap.add_argument("--inflight", type=int, default=3,
                     help="frames in flight per GPU (independent frames on separate HIP streams/contexts)")
     return ap.parse_args()
@@ -67,6 +70,9 @@ def main():
     else:
         sensors, params = synth.config3(min_pts=args.min_pts)
         workload = "cfg3: 8 x 2M XYZI float32 points, yaw-only SE(3), 2 cm voxel, reference ROI crop"
+    if args.outlier_radius > 0:
+        params.outlier_radius, params.outlier_min_neighbors = args.outlier_radius, 1
+        workload += f" + radius outlier removal r={args.outlier_radius} m, min 1 neighbour"
     if rank:
         rng = np.random.default_rng(900 + rank)
         for s in sensors:                      # another frame of the same scene statistics

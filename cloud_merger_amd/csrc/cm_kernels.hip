@@ -1215,33 +1215,95 @@ __global__ __launch_bounds__(CM_BLOCK) void k_neighbors(const CmFrameDev* __rest
     const uint32_t* __restrict__ keys = pick(st, keys_a, keys_b);
     const float r2 = fd->outlier_r2;
     const uint32_t need = fd->outlier_min_nb;            // keep iff k > need, k counts the point itself
+    const float cell = 1.0f / fd->inv_cell[0];
+    const float fb0 = static_cast<float>(st->min_b[0]), fb1 = static_cast<float>(st->min_b[1]),
+                fb2 = static_cast<float>(st->min_b[2]);
     for (uint32_t p = blockIdx.x * CM_BLOCK + threadIdx.x; p < n; p += gridDim.x * CM_BLOCK) {
         const uint32_t key = keys[p];
         const float4 me = sorted_pts[p];
-        const uint32_t i = key % dx, jk = key / dx, j = jk % dy, k = jk / dy;
-        const uint32_t i_lo = i ? i - 1 : 0u, i_hi = (i + 1 < dx) ? i + 1 : dx - 1;
-        uint32_t cnt = 0;
-        for (int dk = -1; dk <= 1 && cnt <= need; ++dk) {
-            const int kk = static_cast<int>(k) + dk;
-            if (kk < 0 || kk >= static_cast<int>(dz)) continue;
-            for (int dj = -1; dj <= 1 && cnt <= need; ++dj) {
-                const int jj = static_cast<int>(j) + dj;
-                if (jj < 0 || jj >= static_cast<int>(dy)) continue;
-                const uint32_t row = static_cast<uint32_t>(jj) + static_cast<uint32_t>(kk) * dy;
-                const uint2 range = rows[row];
-                if (range.x >= range.y) continue;
-                const uint32_t lo_key = row * dx + i_lo, hi_key = row * dx + i_hi;
-                uint32_t a = range.x, b = range.y;           // first position with key >= lo_key
-                while (a < b) {
-                    const uint32_t mid = (a + b) >> 1;
-                    if (keys[mid] < lo_key) a = mid + 1; else b = mid;
+        const uint32_t jk = key / dx, i = key - jk * dx, k = jk / dy, j = jk - k * dy;
+        uint32_t cnt = 1;                                         // the point itself (distance 0)
+        auto test = [&](const float4& pt) {
+            const float ex = __fsub_rn(me.x, pt.x), ey = __fsub_rn(me.y, pt.y), ez = __fsub_rn(me.z, pt.z);
+            return __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez)) < r2;
+        };
+        // Own row first, outward from the point's own sorted position: the points of its own cell
+        // are its immediate neighbours in the sorted order (no search, early exit for most points).
+        {
+            const uint32_t lo_key = jk * dx + (i ? i - 1 : 0u), hi_key = jk * dx + ((i + 1 < dx) ? i + 1 : dx - 1);
+            for (uint32_t q = p + 1; q < n && cnt <= need; ++q) {
+                if (keys[q] > hi_key) break;
+                if (test(sorted_pts[q])) ++cnt;
+            }
+            for (uint32_t q = p; q > 0 && cnt <= need;) {
+                --q;
+                if (keys[q] < lo_key) break;
+                if (test(sorted_pts[q])) ++cnt;
+            }
+        }
+        if (cnt <= need) {
+            // Distance from the point to the faces of its own cell, shrunk by 1 % of a cell so fp32
+            // rounding of the cell coordinates can only make the pruning below more cautious.
+            const float ux = __fsub_rn(__fmul_rn(me.x, fd->inv_cell[0]), __fadd_rn(fb0, static_cast<float>(i)));
+            const float uy = __fsub_rn(__fmul_rn(me.y, fd->inv_cell[1]), __fadd_rn(fb1, static_cast<float>(j)));
+            const float uz = __fsub_rn(__fmul_rn(me.z, fd->inv_cell[2]), __fadd_rn(fb2, static_cast<float>(k)));
+            auto gap = [&](float u, int d) {                      // metres to the neighbouring cell in direction d
+                const float g = (d < 0) ? u : (d > 0) ? (1.0f - u) : 0.0f;
+                return fmaxf(g - 0.01f, 0.0f) * cell;
+            };
+            // The eight rows around it: their lookups and binary searches advance together, so the
+            // dependent-load chain is one search deep instead of eight. Rows and end cells that lie
+            // farther than the radius are skipped.
+            uint32_t a[8], b[8], end[8], hi[8];
+            uint32_t lo[8];
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                const int t = o < 4 ? o : o + 1;
+                const int dj = (t % 3) - 1, dk = (t / 3) - 1;
+                const int jj = static_cast<int>(j) + dj, kk = static_cast<int>(k) + dk;
+                const float gy = gap(uy, dj), gz = gap(uz, dk);
+                const float g2 = gy * gy + gz * gz;
+                const bool ok = kk >= 0 && kk < static_cast<int>(dz) && jj >= 0 && jj < static_cast<int>(dy) && g2 < r2;
+                const uint32_t row = ok ? static_cast<uint32_t>(jj) + static_cast<uint32_t>(kk) * dy : 0u;
+                const uint2 range = ok ? rows[row] : make_uint2(0u, 0u);
+                const float gl = gap(ux, -1), gh = gap(ux, 1);
+                const uint32_t il = (i && gl * gl + g2 < r2) ? i - 1 : i;
+                const uint32_t ih = (i + 1 < dx && gh * gh + g2 < r2) ? i + 1 : i;
+                lo[o] = row * dx + il; hi[o] = row * dx + ih;
+                a[o] = range.x; b[o] = range.y; end[o] = range.y;
+            }
+            for (int step = 0; step < 32; ++step) {
+                bool any = false;
+#pragma unroll
+                for (int o = 0; o < 8; ++o) {
+                    if (a[o] < b[o]) {
+                        const uint32_t mid = (a[o] + b[o]) >> 1;
+                        if (keys[mid] < lo[o]) a[o] = mid + 1; else b[o] = mid;
+                        any = true;
+                    }
                 }
-                for (uint32_t q = a; q < range.y && cnt <= need; ++q) {
-                    if (keys[q] > hi_key) break;
-                    const float4 o = sorted_pts[q];
-                    const float ex = __fsub_rn(me.x, o.x), ey = __fsub_rn(me.y, o.y), ez = __fsub_rn(me.z, o.z);
-                    const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez));
-                    if (d2 < r2) ++cnt;
+                if (!any) break;
+            }
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                uint32_t q = a[o];
+                const uint32_t e = end[o], hk = hi[o];
+                while (q + 4 <= e && cnt <= need) {                // four candidates per step: loads overlap
+                    const uint32_t k0 = keys[q], k1 = keys[q + 1], k2 = keys[q + 2], k3 = keys[q + 3];
+                    const float4 p0 = sorted_pts[q], p1 = sorted_pts[q + 1], p2 = sorted_pts[q + 2], p3 = sorted_pts[q + 3];
+                    if (k0 > hk) { q = e; break; }
+                    if (test(p0)) ++cnt;
+                    if (k1 > hk) { q = e; break; }
+                    if (test(p1)) ++cnt;
+                    if (k2 > hk) { q = e; break; }
+                    if (test(p2)) ++cnt;
+                    if (k3 > hk) { q = e; break; }
+                    if (test(p3)) ++cnt;
+                    q += 4;
+                }
+                for (; q < e && cnt <= need; ++q) {
+                    if (keys[q] > hk) break;
+                    if (test(sorted_pts[q])) ++cnt;
                 }
             }
         }

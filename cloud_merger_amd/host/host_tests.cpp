@@ -86,6 +86,10 @@ static void test_reference_config() {
     CHECK(c.params.crop_min[0] == -15.0f && c.params.crop_max[0] == 60.0f);
     CHECK(c.params.crop_min[1] == -5.0f && c.params.crop_max[1] == 5.0f);
     CHECK(c.params.crop_min[2] == -0.5f && c.params.crop_max[2] == 3.0f);
+    CHECK(c.params.outlier_enable == 0);
+    const NodeConfig f = fusion_config();
+    CHECK(f.params.outlier_enable == 1 && f.params.outlier_radius == 0.1f && f.params.outlier_min_neighbors == 1);
+    CHECK(f.sensors.size() == 6 && f.params.crop_enable == 1);
 }
 
 static void test_node_without_gpu_fails_loudly(bool expect_gpu) {

@@ -26,6 +26,20 @@ NodeConfig reference_config() {
     p.crop_min[0] = -roi_mid;        p.crop_max[0] = roi_length - roi_mid;
     p.crop_min[1] = -roi_width / 2;  p.crop_max[1] = roi_width / 2;
     p.crop_min[2] = -0.5f;           p.crop_max[2] = 3.0f;                 // Parameter.h:34-35
+    // Radius outlier removal is off here: the live node applies it per ground-removal zone
+    // (:119, out of scope). fusion_config() below is the class-based node's chain, which runs it
+    // on the fused cloud.
+    return c;
+}
+
+NodeConfig fusion_config() {
+    // my_cloud_fusion/src/cloud_fusion_node.cpp:72-75: remove_outliers, then voxelgrid, on the
+    // fused cloud; constants from my_cloud_fusion/src/Parameter.h:15-16,109-110.
+    NodeConfig c = reference_config();
+    c.voxel_topic = "/cloud_fusion_node/points_voxel";
+    c.params.outlier_enable = 1;
+    c.params.outlier_radius = 0.1f;
+    c.params.outlier_min_neighbors = 1;
     return c;
 }
 

@@ -3,8 +3,9 @@
 // pcl_preprocessing/src/pc_preprocessing_main.cpp (main :509-587, callbacks :318-508) on top of
 // the C-ABI in include/cloudmerge.h; every numeric step runs in libcloudmerge_hip.so.
 //
-// What is deliberately NOT here: ROI zoning, RANSAC ground removal and radius outlier removal
-// (:49-122, :184-192, :228-312) — SURVEY.md §8f "next" rows, outside the north-star path.
+// What is deliberately NOT here: ROI zoning and RANSAC ground removal (:49-122, :228-312) —
+// SURVEY.md §8f "next" rows, outside the north-star path. Radius outlier removal on the fused cloud
+// (§8f rank 2) is available through cm_params.outlier_*.
 #pragma once
 #include <atomic>
 #include <cstdint>
@@ -39,6 +40,9 @@ struct NodeConfig {
 // The reference's literals: six sensors in fuse order fr, fl, rr, rl, tm, livox (:137-142), ROI
 // crop (Parameter.h:31-35), leaf 0.1 m, min 2 points per voxel (Parameter.h:27-28).
 NodeConfig reference_config();
+// The class-based variant (my_cloud_fusion): same sensors and ROI, plus radius outlier removal on the
+// fused cloud before VoxelGrid (cloud_fusion_node.cpp:72-75).
+NodeConfig fusion_config();
 
 class CloudMergerNode {
 public:

@@ -4,7 +4,8 @@
 // per GPU, no collective).
 //
 //   cloudmerge_replay --dir SEQ --sensors 4 --frames 100 [--leaf 0.05] [--min-pts 2]
-//                     [--crop x0 y0 z0 x1 y1 z1] [--out OUTDIR] [--device 0] [--shard 0/1]
+//                     [--crop x0 y0 z0 x1 y1 z1] [--outlier RADIUS MIN_NEIGHBOURS] [--out OUTDIR]
+//                     [--device 0] [--shard 0/1]
 //                     [--rate 10 --realtime]
 // SEQ/transforms.txt : one line per sensor "qx qy qz qw tx ty tz" (tf lookup results)
 // SEQ/frame_%04d_sensor_%d.pcd : FIELDS x y z [intensity], FLOAT32
@@ -46,6 +47,10 @@ int main(int argc, char** argv) {
             cfg.params.crop_enable = 1;
             for (int i = 0; i < 3; ++i) cfg.params.crop_min[i] = std::strtof(next(), nullptr);
             for (int i = 0; i < 3; ++i) cfg.params.crop_max[i] = std::strtof(next(), nullptr);
+        } else if (k == "--outlier") {                       // radius, min neighbours (CloudFusionNode.h:74-85)
+            cfg.params.outlier_enable = 1;
+            cfg.params.outlier_radius = std::strtof(next(), nullptr);
+            cfg.params.outlier_min_neighbors = static_cast<uint32_t>(std::atoi(next()));
         } else if (k == "--shard") {
             if (std::sscanf(next(), "%d/%d", &rank, &world) != 2 || world < 1 || rank < 0 || rank >= world) { std::fprintf(stderr, "bad --shard\n"); return 2; }
         } else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
