@@ -413,3 +413,50 @@ def test_outlier_radius_too_small_is_an_error():
         params.outlier_radius = None                      # the context stays usable
         cm.submit_all(sensors)
         assert cm.merge_voxelize(params).status == capi.OK
+
+
+def test_concurrent_ingest_threads_and_consumer():
+    """The calling pattern of the reference node: one ingest thread per sensor (AsyncSpinner(6), :513)
+    calling cm_submit_cloud while the main loop calls cm_merge_voxelize (:574-577). Every fused frame
+    must be made of whole clouds (no torn frame): each sensor alternates between two clouds of known
+    voxel counts, so n_in/n_out of any frame must be one of the valid combinations."""
+    import threading
+    rng = np.random.default_rng(11)
+    n_sensors, variants = 4, 2
+    clouds = [[xyzi_cloud(rng.uniform(10 * s, 10 * s + 5, (3000 + 500 * v, 3)), np.full(3000 + 500 * v, float(v)))
+               for v in range(variants)] for s in range(n_sensors)]
+    params = MergeParams(leaf=(0.5,) * 3, min_points_per_voxel=0)
+    stop = threading.Event()
+    errors = []
+    with capi.CloudMerger(max_points_total=n_sensors * 4000, max_sensors=n_sensors) as cm:
+        def ingest(s):
+            k = 0
+            try:
+                while not stop.is_set():
+                    cm.submit(s, clouds[s][k % variants])
+                    k += 1
+            except Exception as e:        # pragma: no cover
+                errors.append(e)
+        threads = [threading.Thread(target=ingest, args=(s,)) for s in range(n_sensors)]
+        for t in threads:
+            t.start()
+        fused, sizes = 0, set()
+        try:
+            for _ in range(300):
+                res = cm.merge_voxelize(params)
+                if res.status == capi.NOT_READY:
+                    continue
+                assert res.status == capi.OK
+                fused += 1
+                sizes.add(int(res.n_in))
+                # sensors occupy disjoint regions, intensity = variant id: per-voxel intensity must be 0 or 1
+                out = cm.result(res.n_out)
+                assert np.all((out["intensity"] == 0.0) | (out["intensity"] == 1.0)), "torn cloud"
+        finally:
+            stop.set()
+            for t in threads:
+                t.join()
+    assert not errors, errors
+    assert fused > 20
+    valid = {sum(3000 + 500 * v for v in combo) for combo in np.ndindex(*(variants,) * n_sensors)}
+    assert sizes <= valid, sizes - valid
