@@ -18,7 +18,7 @@ MAX_SENSORS = 16
 NO_FIELD = 0xFFFFFFFF
 MAX_STAGES = 32
 
-OK, EMPTY_INPUT, GRID_OVERFLOW, NOT_READY = 0, 1, 2, 3
+OK, EMPTY_INPUT, GRID_OVERFLOW, NOT_READY, SKIPPED = 0, 1, 2, 3, 4
 BAD_ARG, HIP_ERROR, NO_DEVICE, CAPACITY, INTERNAL = -1, -2, -3, -4, -5
 FLAG_PROFILE, FLAG_LATEST_WINS, FLAG_OCCUPANCY = 0x1, 0x2, 0x4
 
@@ -199,13 +199,15 @@ class CloudMerger:
     def submit(self, sensor, cloud: SensorCloud):
         data = np.ascontiguousarray(cloud.data)
         off_i = NO_FIELD if cloud.off_i is None else cloud.off_i
-        self._check(self._lib.cm_submit_cloud(self._ctx, sensor, data.ctypes.data, cloud.n, cloud.point_step,
-                                              cloud.off_x, cloud.off_y, cloud.off_z, off_i), "cm_submit_cloud")
+        return self._check(self._lib.cm_submit_cloud(self._ctx, sensor, data.ctypes.data, cloud.n, cloud.point_step,
+                                                     cloud.off_x, cloud.off_y, cloud.off_z, off_i), "cm_submit_cloud",
+                           ok=(OK, SKIPPED))
 
     def submit_device(self, sensor, dev_ptr, n, point_step=16, off_x=0, off_y=4, off_z=8, off_i=12):
         off_i = NO_FIELD if off_i is None else off_i
-        self._check(self._lib.cm_submit_cloud_device(self._ctx, sensor, C.c_void_p(dev_ptr), n, point_step,
-                                                     off_x, off_y, off_z, off_i), "cm_submit_cloud_device")
+        return self._check(self._lib.cm_submit_cloud_device(self._ctx, sensor, C.c_void_p(dev_ptr), n, point_step,
+                                                            off_x, off_y, off_z, off_i), "cm_submit_cloud_device",
+                           ok=(OK, SKIPPED))
 
     def clear(self, sensor):
         self._check(self._lib.cm_clear_sensor(self._ctx, sensor), "cm_clear_sensor")

@@ -105,6 +105,7 @@ const char* k_status_names(int s) {
         case CM_EMPTY_INPUT: return "CM_EMPTY_INPUT";
         case CM_GRID_OVERFLOW: return "CM_GRID_OVERFLOW";
         case CM_NOT_READY: return "CM_NOT_READY";
+        case CM_SKIPPED: return "CM_SKIPPED";
         case CM_BAD_ARG: return "CM_BAD_ARG";
         case CM_HIP_ERROR: return "CM_HIP_ERROR";
         case CM_NO_DEVICE: return "CM_NO_DEVICE";
@@ -204,7 +205,7 @@ int set_slot_cloud(cm_ctx* c, uint32_t sensor, const void* data, bool on_device,
     HIP_TRY(c, hipSetDevice(c->device));
     Slot& s = c->slots[sensor];
     std::lock_guard<std::mutex> lk(s.mu);
-    if (s.fresh && !(c->flags & CM_FLAG_LATEST_WINS)) return CM_OK;   // first since last fuse wins
+    if (s.fresh && !(c->flags & CM_FLAG_LATEST_WINS)) return CM_SKIPPED;   // first since last fuse wins
     if (c->in_flight.load()) HIP_TRY(c, hipEventSynchronize(c->ev_done));
     const size_t bytes = static_cast<size_t>(n) * step;
     if (on_device) {

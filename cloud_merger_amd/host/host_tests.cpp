@@ -92,6 +92,29 @@ static void test_reference_config() {
     CHECK(f.sensors.size() == 6 && f.params.crop_enable == 1);
 }
 
+static void test_load_config(const char* tmpdir) {
+    const std::string path = std::string(tmpdir) + "/node.cfg";
+    FILE* f = std::fopen(path.c_str(), "w");
+    std::fprintf(f, "# two sensors\nsensor left /left/points /lidar_left required\nsensor right /right/points /lidar_right optional\n"
+                    "leaf 0.05\nmin_points_per_voxel 3\ncrop -1 -2 -3 4 5 6\noutlier 0.2 2\nstamp_from_inputs 1\nrate_hz 20\n"
+                    "voxel_topic /voxels\nmax_points_total 123456\n");
+    std::fclose(f);
+    NodeConfig c;
+    std::string err;
+    CHECK(load_config(path, &c, &err));
+    CHECK(c.sensors.size() == 2 && c.sensors[1].topic == "/right/points" && !c.sensors[1].required && c.sensors[0].required);
+    CHECK(c.params.leaf[2] == 0.05f && c.params.min_points_per_voxel == 3 && c.params.crop_enable == 1);
+    CHECK(c.params.crop_min[2] == -3.0f && c.params.crop_max[0] == 4.0f);
+    CHECK(c.params.outlier_enable == 1 && c.params.outlier_radius == 0.2f && c.params.outlier_min_neighbors == 2);
+    CHECK(c.stamp_from_inputs && c.rate_hz == 20.0 && c.voxel_topic == "/voxels" && c.max_points_total == 123456);
+    CHECK(c.base_frame == "base_footprint");                      // untouched keys keep the reference's values
+    f = std::fopen(path.c_str(), "w");
+    std::fprintf(f, "leaf -1\n");
+    std::fclose(f);
+    CHECK(!load_config(path, &c, &err) && err.find(":1:") != std::string::npos);
+    CHECK(!load_config(std::string(tmpdir) + "/nope.cfg", &c, &err));
+}
+
 static void test_node_without_gpu_fails_loudly(bool expect_gpu) {
     NodeConfig c = reference_config();
     c.max_points_total = 1000;
@@ -103,6 +126,29 @@ static void test_node_without_gpu_fails_loudly(bool expect_gpu) {
         PointCloud2 m = make_xyzi16_message(4);
         CHECK(node.on_cloud(0, m) == CM_NOT_READY);                        // transforms not looked up yet
         CHECK(node.spin_once() == CM_NOT_READY);
+        // stamp policy + "first since last fuse wins" through the node (two sensors, no crop)
+        NodeConfig c2;
+        c2.sensors = {{"a", "/a", "/fa", true}, {"b", "/b", "/fb", true}};
+        c2.params.leaf[0] = c2.params.leaf[1] = c2.params.leaf[2] = 0.5f;
+        c2.params.downsample_all_data = 1;
+        c2.max_points_total = 1000;
+        c2.stamp_from_inputs = true;
+        CloudMergerNode n2(c2);
+        CHECK(n2.ok());
+        const double q[4] = {0, 0, 0, 1}, t[3] = {0, 0, 0};
+        n2.set_transform(0, q, t); n2.set_transform(1, q, t);
+        uint64_t got_stamp = 0; size_t got_pts = 0; std::string got_frame;
+        n2.set_publisher([&](const std::string&, const PointCloud2& out) { got_stamp = out.header.stamp_ns; got_pts = out.num_points(); got_frame = out.header.frame_id; });
+        PointCloud2 ca = make_xyzi16_message(2), cb = make_xyzi16_message(1), cc = make_xyzi16_message(1);
+        const float pa[8] = {0.1f, 0.1f, 0.1f, 1.f, 0.2f, 0.2f, 0.2f, 3.f}, pb[4] = {5.f, 5.f, 5.f, 7.f}, pc[4] = {9.f, 9.f, 9.f, 9.f};
+        std::memcpy(ca.data.data(), pa, 32); std::memcpy(cb.data.data(), pb, 16); std::memcpy(cc.data.data(), pc, 16);
+        ca.header.stamp_ns = 1000; cb.header.stamp_ns = 2500; cc.header.stamp_ns = 9999;
+        CHECK(n2.on_cloud(0, ca) == CM_OK);
+        CHECK(n2.spin_once() == CM_NOT_READY);                             // sensor b still missing (:134)
+        CHECK(n2.on_cloud(1, cb) == CM_OK);
+        CHECK(n2.on_cloud(1, cc) == CM_OK);                                // dropped: b already holds a fresh cloud (:356)
+        CHECK(n2.spin_once() == CM_OK);
+        CHECK(got_pts == 2 && got_stamp == 2500 && got_frame == "base_footprint");   // stamp of the newest FUSED cloud
     } else {
         CHECK(!node.ok() && !node.error().empty());
         CHECK(node.spin_once() == CM_NO_DEVICE);
@@ -115,6 +161,7 @@ int main(int argc, char** argv) {
     test_find_xyzi();
     test_pcd_roundtrip(tmpdir);
     test_reference_config();
+    test_load_config(tmpdir);
     test_node_without_gpu_fails_loudly(expect_gpu);
     std::printf("%s (%d failures)\n", failures ? "FAILED" : "ok", failures);
     return failures ? 1 : 0;

@@ -2,6 +2,9 @@
 #include "merger_node.hpp"
 
 #include <chrono>
+#include <algorithm>
+#include <fstream>
+#include <sstream>
 #include <thread>
 
 namespace cloudmerge {
@@ -43,8 +46,52 @@ NodeConfig fusion_config() {
     return c;
 }
 
-CloudMergerNode::CloudMergerNode(const NodeConfig& cfg) : cfg_(cfg), have_tf_(cfg.sensors.size()) {
+bool load_config(const std::string& path, NodeConfig* cfg, std::string* err) {
+    std::ifstream f(path);
+    if (!f) { if (err) *err = "cannot open " + path; return false; }
+    NodeConfig c = reference_config();
+    bool own_sensors = false;
+    int lineno = 0;
+    for (std::string line; std::getline(f, line);) {
+        ++lineno;
+        const size_t hash = line.find('#');
+        if (hash != std::string::npos) line.resize(hash);
+        std::istringstream is(line);
+        std::string key;
+        if (!(is >> key)) continue;
+        bool ok = true;
+        if (key == "sensor") {
+            SensorSpec s;
+            std::string req;
+            ok = static_cast<bool>(is >> s.name >> s.topic >> s.frame >> req) && (req == "required" || req == "optional");
+            s.required = req == "required";
+            if (ok) { if (!own_sensors) { c.sensors.clear(); own_sensors = true; } c.sensors.push_back(s); }
+        } else if (key == "base_frame") ok = static_cast<bool>(is >> c.base_frame);
+        else if (key == "voxel_topic") ok = static_cast<bool>(is >> c.voxel_topic);
+        else if (key == "rate_hz") ok = static_cast<bool>(is >> c.rate_hz) && c.rate_hz > 0;
+        else if (key == "leaf") { float v; ok = static_cast<bool>(is >> v) && v > 0; if (ok) c.params.leaf[0] = c.params.leaf[1] = c.params.leaf[2] = v; }
+        else if (key == "min_points_per_voxel") ok = static_cast<bool>(is >> c.params.min_points_per_voxel);
+        else if (key == "crop") {
+            ok = static_cast<bool>(is >> c.params.crop_min[0] >> c.params.crop_min[1] >> c.params.crop_min[2] >>
+                                   c.params.crop_max[0] >> c.params.crop_max[1] >> c.params.crop_max[2]);
+            c.params.crop_enable = 1;
+        } else if (key == "no_crop") c.params.crop_enable = 0;
+        else if (key == "outlier") { ok = static_cast<bool>(is >> c.params.outlier_radius >> c.params.outlier_min_neighbors); c.params.outlier_enable = 1; }
+        else if (key == "stamp_from_inputs") { int v; ok = static_cast<bool>(is >> v); c.stamp_from_inputs = v != 0; }
+        else if (key == "max_points_total") ok = static_cast<bool>(is >> c.max_points_total);
+        else if (key == "device") ok = static_cast<bool>(is >> c.device);
+        else ok = false;
+        if (!ok) { if (err) *err = path + ":" + std::to_string(lineno) + ": bad line"; return false; }
+    }
+    if (c.sensors.empty() || c.sensors.size() > CM_MAX_SENSORS) { if (err) *err = "sensor count must be 1..16"; return false; }
+    *cfg = c;
+    return true;
+}
+
+CloudMergerNode::CloudMergerNode(const NodeConfig& cfg)
+    : cfg_(cfg), have_tf_(cfg.sensors.size()), stamp_ns_(cfg.sensors.size()) {
     for (auto& f : have_tf_) f.store(false);
+    for (auto& t : stamp_ns_) t.store(0);
     if (cfg_.sensors.empty() || cfg_.sensors.size() > CM_MAX_SENSORS) {
         error_ = "sensor count must be 1..CM_MAX_SENSORS";
         return;
@@ -96,8 +143,10 @@ int CloudMergerNode::on_cloud(size_t sensor, const PointCloud2& msg) {
     if (!transforms_ready()) return CM_NOT_READY;
     const XyziLayout l = find_xyzi(msg);
     if (!l.ok) { error_ = l.error; return CM_BAD_ARG; }
-    return cm_submit_cloud(ctx_, static_cast<uint32_t>(sensor), msg.data.data(),
-                           static_cast<uint32_t>(msg.num_points()), msg.point_step, l.off_x, l.off_y, l.off_z, l.off_i);
+    const int st = cm_submit_cloud(ctx_, static_cast<uint32_t>(sensor), msg.data.data(),
+                                   static_cast<uint32_t>(msg.num_points()), msg.point_step, l.off_x, l.off_y, l.off_z, l.off_i);
+    if (st == CM_OK) stamp_ns_[sensor].store(msg.header.stamp_ns);   // CM_SKIPPED: the slot keeps its older cloud
+    return st == CM_SKIPPED ? CM_OK : st;
 }
 
 int CloudMergerNode::spin_once(cm_result* res) {
@@ -115,7 +164,9 @@ int CloudMergerNode::spin_once(cm_result* res) {
         if (cs != CM_OK) { error_ = cm_last_error(ctx_); return cs; }
     }
     msg.header.seq = seq_++;
-    msg.header.stamp_ns = clock_();
+    uint64_t newest = 0;
+    for (const auto& t : stamp_ns_) newest = std::max(newest, t.load());
+    msg.header.stamp_ns = (cfg_.stamp_from_inputs && newest) ? newest : clock_();
     msg.header.frame_id = cfg_.base_frame;
     if (publish_) publish_(cfg_.voxel_topic, msg);
     frames_.fetch_add(1);

@@ -35,7 +35,20 @@ struct NodeConfig {
     int device = 0;
     uint32_t flags = 0;
     bool publish_pcl_layout = true;                 // 32-byte pcl::PointXYZI records like pcl::toROSMsg
+    // Stamp of the published cloud. false: ros::Time::now() at publish like the reference (:217).
+    // true: the newest stamp among the fused input clouds — what pcl::PointCloud::operator+= leaves in
+    // the fused cloud's header and what §8f rank 4 proposes.
+    bool stamp_from_inputs = false;
 };
+
+// Loads a node description from a text file (an N-sensor configuration instead
+// of the reference's string literals). Lines, '#' comments allowed:
+//   sensor <name> <topic> <tf_frame> <required|optional>
+//   base_frame <id> | voxel_topic <topic> | rate_hz <v> | leaf <v> | min_points_per_voxel <n>
+//   crop <x0> <y0> <z0> <x1> <y1> <z1> | outlier <radius> <min_neighbors> | stamp_from_inputs <0|1>
+//   max_points_total <n> | device <n>
+// Starts from reference_config() minus its sensors when the file names any. Returns false + *err.
+bool load_config(const std::string& path, NodeConfig* cfg, std::string* err);
 
 // The reference's literals: six sensors in fuse order fr, fl, rr, rl, tm, livox (:137-142), ROI
 // crop (Parameter.h:31-35), leaf 0.1 m, min 2 points per voxel (Parameter.h:27-28).
@@ -90,6 +103,7 @@ private:
     std::string error_;
     std::atomic<uint64_t> frames_{0};
     uint32_t seq_ = 0;
+    std::vector<std::atomic<uint64_t>> stamp_ns_;   // stamp of the cloud each sensor slot currently holds
 };
 
 }  // namespace cloudmerge

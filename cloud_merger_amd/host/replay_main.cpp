@@ -3,7 +3,7 @@
 // config 4: frames are independent, so `--shard r/w` gives rank r every w-th frame (one process
 // per GPU, no collective).
 //
-//   cloudmerge_replay --dir SEQ --sensors 4 --frames 100 [--leaf 0.05] [--min-pts 2]
+//   cloudmerge_replay --dir SEQ --sensors 4 --frames 100 [--config NODE.cfg] [--leaf 0.05] [--min-pts 2]
 //                     [--crop x0 y0 z0 x1 y1 z1] [--outlier RADIUS MIN_NEIGHBOURS] [--out OUTDIR]
 //                     [--device 0] [--shard 0/1]
 //                     [--rate 10 --realtime]
@@ -26,7 +26,7 @@ int main(int argc, char** argv) {
     std::string dir, out_dir;
     int n_sensors = 4, n_frames = 1, device = 0, rank = 0, world = 1;
     double rate = 10.0;
-    bool realtime = false;
+    bool realtime = false, have_config = false;
     NodeConfig cfg;
     cfg.params.leaf[0] = cfg.params.leaf[1] = cfg.params.leaf[2] = 0.05f;
     cfg.params.min_points_per_voxel = 2;
@@ -34,7 +34,12 @@ int main(int argc, char** argv) {
     for (int a = 1; a < argc; ++a) {
         const std::string k = argv[a];
         auto next = [&](int n = 1) { if (a + n >= argc) { std::fprintf(stderr, "missing value for %s\n", k.c_str()); std::exit(2); } return argv[++a]; };
-        if (k == "--dir") dir = next();
+        if (k == "--config") {                                // node description file (merger_node.hpp: load_config)
+            std::string e;
+            if (!load_config(next(), &cfg, &e)) { std::fprintf(stderr, "%s\n", e.c_str()); return 2; }
+            n_sensors = static_cast<int>(cfg.sensors.size());
+            have_config = true;
+        } else if (k == "--dir") dir = next();
         else if (k == "--out") out_dir = next();
         else if (k == "--sensors") n_sensors = std::atoi(next());
         else if (k == "--frames") n_frames = std::atoi(next());
@@ -57,8 +62,9 @@ int main(int argc, char** argv) {
     }
     if (dir.empty() || n_sensors < 1 || n_sensors > CM_MAX_SENSORS) { std::fprintf(stderr, "usage: see header of replay_main.cpp\n"); return 2; }
 
-    for (int s = 0; s < n_sensors; ++s)
-        cfg.sensors.push_back({"sensor" + std::to_string(s), "/sensor" + std::to_string(s) + "/points", "/sensor" + std::to_string(s), true});
+    if (!have_config)
+        for (int s = 0; s < n_sensors; ++s)
+            cfg.sensors.push_back({"sensor" + std::to_string(s), "/sensor" + std::to_string(s) + "/points", "/sensor" + std::to_string(s), true});
     cfg.device = device;
     cfg.rate_hz = rate;
     cfg.max_points_total = 0;

@@ -42,6 +42,8 @@ typedef enum cm_status {
     CM_EMPTY_INPUT = 1,    /* no point survived: PCL VoxelGrid returns width = height = 0 */
     CM_GRID_OVERFLOW = 2,  /* PCL's int32 index guard tripped: output = merged input, unvoxelised */
     CM_NOT_READY = 3,      /* a required sensor has no fresh cloud: the reference skips the tick (:134,:575) */
+    CM_SKIPPED = 4,        /* cm_submit_cloud*: this sensor already holds an unconsumed cloud and the policy is
+                              "first since the last fuse wins" (:330): the new one was dropped */
     CM_BAD_ARG = -1,
     CM_HIP_ERROR = -2,
     CM_NO_DEVICE = -3,

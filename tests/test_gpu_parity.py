@@ -264,8 +264,8 @@ def test_not_ready_until_required_sensors_fresh():
         r = cm.merge_voxelize(p)
         assert r.status == capi.OK and r.n_in == 150 and r.n_sensors == 2
         assert cm.merge_voxelize(p).status == capi.NOT_READY          # flags were reset by the fuse
-        cm.submit(0, a)
-        cm.submit(0, xyzi_cloud(rng.uniform(5, 6, (10, 3))))           # ignored: first since last fuse wins
+        assert cm.submit(0, a) == capi.OK
+        assert cm.submit(0, xyzi_cloud(rng.uniform(5, 6, (10, 3)))) == capi.SKIPPED   # first since last fuse wins
         cm.submit(1, b)
         r2 = cm.merge_voxelize(p)
         assert r2.status == capi.OK and r2.n_in == 150
