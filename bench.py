@@ -35,6 +35,10 @@ def parse():
     ap.add_argument("--config", type=int, default=2, choices=[2, 3])
     ap.add_argument("--min-pts", type=int, default=2, help="min points per voxel (reference: 2, PCL default: 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal: every rank uses GPU 0 (needs --backend gloo; not a measurement)")
     ap.add_argument("--profile-frames", type=int, default=20)
     ap.add_argument("--outlier-radius", type=float, default=0.0,
                     help="also run pcl::RadiusOutlierRemoval (min 1 neighbour) on the fused cloud before VoxelGrid "
@@ -56,10 +60,15 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from cloud_merger_amd import capi, synth
 
@@ -136,7 +145,7 @@ def main():
         raise SystemExit(f"frame status {capi.status_string(res.status)}")
     n_out = int(res.n_out)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
