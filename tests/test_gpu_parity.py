@@ -460,3 +460,50 @@ def test_concurrent_ingest_threads_and_consumer():
     assert fused > 20
     valid = {sum(3000 + 500 * v for v in combo) for combo in np.ndindex(*(variants,) * n_sensors)}
     assert sizes <= valid, sizes - valid
+
+
+# ---- seeded randomized differential test ------------------------------------------------------
+def _random_scenario(seed):
+    rng = np.random.default_rng(seed)
+    n_sensors = int(rng.integers(1, 7))
+    layouts = ["xyzi16", "pcl32", "velo22", "xyz12"]
+    scale = float(rng.choice([0.5, 3.0, 20.0]))
+    sensors = []
+    for s in range(n_sensors):
+        n = int(rng.choice([0, 1, 7, 300, 5000, 9000]))
+        xyz = rng.uniform(-scale, scale, (n, 3)).astype(np.float32)
+        if n and rng.random() < 0.5:                      # clusters: several points per voxel
+            xyz[: n // 2] = (rng.integers(-3, 4, (n // 2, 3)) * (scale / 4) + rng.normal(0, scale / 200, (n // 2, 3))).astype(np.float32)
+        dense = True
+        if n and rng.random() < 0.3:
+            xyz[rng.integers(0, n, max(1, n // 50))] = np.nan
+            dense = False
+        inten = rng.uniform(0, 255, n).astype(np.float32)
+        data, lay = synth.pack(xyz, inten, str(rng.choice(layouts)))
+        q = synth.random_quaternion(rng) if rng.random() < 0.7 else np.array([0.0, 0.0, 0.0, 1.0])
+        sensors.append(SensorCloud(data=data, n=n, q_xyzw=q, t_xyz=rng.uniform(-1, 1, 3), is_dense=dense, **lay))
+    leaf = float(rng.choice([0.02, 0.1, 0.37, 1.0])) * max(scale / 3.0, 0.2)
+    p = MergeParams(leaf=(leaf, leaf * float(rng.choice([1.0, 1.5])), leaf), min_points_per_voxel=int(rng.choice([0, 1, 2, 3])),
+                    downsample_all_data=bool(rng.random() < 0.8))
+    any_nan = any(not s.is_dense for s in sensors)
+    if rng.random() < 0.5 or any_nan:                     # PCL needs a crop (or !is_dense) to drop NaNs: always crop then
+        c = scale * float(rng.choice([0.4, 0.9, 1.5]))
+        p.crop_min, p.crop_max = (-c, -c, -c * 0.8), (c, c * 0.7, c)
+    if rng.random() < 0.3:
+        p.outlier_radius, p.outlier_min_neighbors = leaf * float(rng.choice([0.8, 2.0])), int(rng.choice([1, 2]))
+    return sensors, p
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_randomized_differential(seed):
+    sensors, params = _random_scenario(1000 + seed)
+    st, merged, out, rep = oracle.merge_voxelize(sensors, params, threads=2, stable=True)
+    g = run_gpu(sensors, params)
+    assert g["res"].status == st, (capi.status_string(g["res"].status), st)
+    assert same_bits(g["merged"], xyzi_of(merged))
+    if st == oracle.OK:
+        assert g["res"].n_out == rep.n_out
+        assert np.array_equal(g["cells"], rep.cells) and np.array_equal(g["counts"], rep.counts)
+        assert_centroids_close(g["out"], xyzi_of(out))
+    elif st == oracle.GRID_OVERFLOW:
+        assert same_bits(g["out"], xyzi_of(out))
