@@ -233,26 +233,44 @@ def main():
         cells_gpu, counts_gpu = cmp.cells(r.n_out)
         cmp.close()
 
-        # PCIe-inclusive figure (never `value`): PointCloud2 payloads in host memory in, compact
-        # result in host memory out, through cm_submit_cloud / cm_result_copy.
+        # PCIe-inclusive figures (never `value`): PointCloud2 payloads in host memory in, compact
+        # result in host memory out, through cm_submit_cloud / cm_result_copy — from pageable memory
+        # (what a ROS callback hands over) and from pinned staging buffers (cm_host_alloc).
         if world == 1:
-            cme = capi.CloudMerger(max_points_total=n_in, max_sensors=len(sensors), device=local_rank)
-            for k, s in enumerate(sensors):
-                cme.set_transform(k, s.q_xyzw, s.t_xyz)
-            t_e2e = []
-            for it in range(7):
-                torch.cuda.synchronize()
-                ta = time.perf_counter()
+            import copy
+            def e2e(cloud_list, reps=7):
+                cme = capi.CloudMerger(max_points_total=n_in, max_sensors=len(sensors), device=local_rank)
                 for k, s in enumerate(sensors):
-                    cme.submit(k, s)
-                re = cme.merge_voxelize(params)
-                host_out = cme.result(re.n_out)
-                t_e2e.append(time.perf_counter() - ta)
-            cme.close()
-            e2e = float(np.median(t_e2e[2:]))
-            out["config"]["e2e_host_buffers"] = {"ms_per_step": 1e3 * e2e, "points_per_s": n_in / e2e,
-                                                 "note": "pageable host payloads -> HBM -> result in host memory "
-                                                         "(H2D + D2H over PCIe included); reported beside, never as, value"}
+                    cme.set_transform(k, s.q_xyzw, s.t_xyz)
+                ts = []
+                for it in range(reps):
+                    torch.cuda.synchronize()
+                    ta = time.perf_counter()
+                    for k, s in enumerate(cloud_list):
+                        cme.submit(k, s)
+                    re = cme.merge_voxelize(params)
+                    cme.result(re.n_out)
+                    ts.append(time.perf_counter() - ta)
+                cme.close()
+                return float(np.median(ts[2:]))
+            t_page = e2e(sensors)
+            holders, pinned = [], []
+            for s in sensors:
+                raw = np.ascontiguousarray(s.data).view(np.uint8).reshape(-1)
+                h = capi.pinned_array(raw.nbytes)
+                h.array[:] = raw
+                holders.append(h)
+                ps = copy.copy(s)
+                ps.data = h.array
+                pinned.append(ps)
+            t_pin = e2e(pinned)
+            for h in holders:
+                h.free()
+            out["config"]["e2e_host_buffers"] = {
+                "pageable_ms_per_step": 1e3 * t_page, "pageable_points_per_s": n_in / t_page,
+                "pinned_ms_per_step": 1e3 * t_pin, "pinned_points_per_s": n_in / t_pin,
+                "note": "host PointCloud2 payloads -> HBM -> result in host memory, one frame at a time "
+                        "(H2D + D2H over PCIe included); reported beside, never as, value"}
 
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle

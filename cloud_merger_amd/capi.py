@@ -145,6 +145,29 @@ def make_params(p: MergeParams) -> Params:
     return cp
 
 
+def pinned_array(nbytes):
+    """uint8 numpy view of nbytes of pinned host memory (cm_host_alloc); keep the returned holder alive
+    and call holder.free() when done."""
+    L = load()
+    ptr = C.c_void_p()
+    st = L.cm_host_alloc(C.byref(ptr), int(nbytes))
+    if st != OK:
+        raise CloudMergeError(st, "cm_host_alloc")
+    buf = (C.c_uint8 * int(nbytes)).from_address(ptr.value)
+    arr = np.frombuffer(buf, dtype=np.uint8)
+
+    class _Holder:
+        def __init__(self):
+            self.array, self.ptr = arr, ptr
+
+        def free(self):
+            if self.ptr:
+                L.cm_host_free(self.ptr)
+                self.ptr = None
+
+    return _Holder()
+
+
 class CloudMerger:
     """Thin object wrapper over a cm_ctx. Mirrors the calling pattern of the reference node:
     set the static transforms once (:556-561), submit one cloud per sensor (callbacks :318-508),
