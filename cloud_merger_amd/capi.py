@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libcloudmerge_hip.so")
 
 MAX_SENSORS = 16
 NO_FIELD = 0xFFFFFFFF
-MAX_STAGES = 32
+MAX_STAGES = 48
 
 OK, EMPTY_INPUT, GRID_OVERFLOW, NOT_READY, SKIPPED = 0, 1, 2, 3, 4
 BAD_ARG, HIP_ERROR, NO_DEVICE, CAPACITY, INTERNAL = -1, -2, -3, -4, -5

@@ -292,12 +292,37 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->pending) return fail(c, CM_BAD_ARG, "previous frame not waited for (cm_wait)");
 
+    // Everything that can reject the call is checked before the frame is assembled: assembling
+    // consumes the sensors' "fresh" flags (:151-157), and a rejected call must not lose a frame.
+    float inv_leaf[3], inv_cell[3] = {0.f, 0.f, 0.f};
+    for (int a = 0; a < 3; ++a) inv_leaf[a] = 1.0f / p->leaf[a];
+    const bool outl = p->outlier_enable != 0;
+    if (outl && mode != 0) return fail(c, CM_BAD_ARG, "outlier removal needs the whole fused cloud on one GPU (not with partial tables)");
+    if (outl && (!(p->outlier_radius > 0.0f) || !std::isfinite(p->outlier_radius))) return fail(c, CM_BAD_ARG, "outlier_radius must be > 0");
+    if (outl) for (int a = 0; a < 3; ++a) inv_cell[a] = 1.0f / (p->outlier_radius * 1.01f);   // candidate grid a little wider than r
+    uint32_t key_bits = 0, kb_o = 0;
+    int grid_mode = 0;                               // 0: data min/max (k_minmax), 1: crop box, 2: bounds handed in
+    if (p->crop_enable && box_grid(p->crop_min, p->crop_max, inv_leaf, &key_bits)) grid_mode = 1;
+    else if (mode == 1 && bounds && box_grid(bounds, bounds + 3, inv_leaf, &key_bits)) grid_mode = 2;
+    else if (mode == 1) return fail(c, CM_BAD_ARG, "partial table needs the crop box or the fused cloud's bounds to fix the grid");
+    int gm_o = 0;                                    // grid of the outlier stage: crop box or data min/max
+    if (outl && p->crop_enable) {
+        if (!box_grid(p->crop_min, p->crop_max, inv_cell, &kb_o))
+            return fail(c, CM_CAPACITY, "outlier radius too small for the crop box (radius grid exceeds 32 bits)");
+        gm_o = 1;
+    }
+
     std::vector<std::unique_lock<std::mutex>> locks;
     const int bf = build_frame(c, p, true, locks);
     if (bf != CM_OK) return bf;
     CmFrameDev& f = c->frame;
     if (mode == 1 && bounds) {
         for (int a = 0; a < 3; ++a) { f.ext_min[a] = bounds[a]; f.ext_max[a] = bounds[3 + a]; }
+    }
+    if (outl) {
+        for (int a = 0; a < 3; ++a) f.inv_cell[a] = inv_cell[a];
+        f.outlier_r2 = static_cast<float>(static_cast<double>(p->outlier_radius) * static_cast<double>(p->outlier_radius));
+        f.outlier_min_nb = p->outlier_min_neighbors;
     }
     c->have_result = false;
     c->out_is_merged = false;
@@ -310,14 +335,6 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
         return CM_OK;
     }
 
-    const bool outl = p->outlier_enable != 0;
-    if (outl && mode != 0) return fail(c, CM_BAD_ARG, "outlier removal needs the whole fused cloud on one GPU (not with partial tables)");
-    if (outl) {
-        if (!(p->outlier_radius > 0.0f) || !std::isfinite(p->outlier_radius)) return fail(c, CM_BAD_ARG, "outlier_radius must be > 0");
-        for (int a = 0; a < 3; ++a) f.inv_cell[a] = 1.0f / (p->outlier_radius * 1.01f);   // candidate grid a little wider than r
-        f.outlier_r2 = static_cast<float>(static_cast<double>(p->outlier_radius) * static_cast<double>(p->outlier_radius));
-        f.outlier_min_nb = p->outlier_min_neighbors;
-    }
     hipStream_t st = c->stream;
     if (!c->frame_uploaded_valid || std::memcmp(&f, &c->frame_uploaded, sizeof f) != 0) {
         prof_mark(c, "k_setup");
@@ -327,11 +344,6 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
     }
     CmFrameState* state = c->d_state[c->cur];
     CmFrameState* state_next = c->d_state[c->cur ^ 1];
-    uint32_t key_bits = 0;
-    int grid_mode = 0;                               // 0: data min/max (k_minmax), 1: crop box, 2: bounds handed in
-    if (f.crop_enable && box_grid(p->crop_min, p->crop_max, f.inv_leaf, &key_bits)) grid_mode = 1;
-    else if (mode == 1 && bounds && box_grid(bounds, bounds + 3, f.inv_leaf, &key_bits)) grid_mode = 2;
-    else if (mode == 1) return fail(c, CM_BAD_ARG, "partial table needs the crop box or the fused cloud's bounds to fix the grid");
     c->from_crop = grid_mode != 0;
     const uint32_t passes = c->from_crop ? (key_bits + CM_RADIX_BITS - 1) / CM_RADIX_BITS : CM_MAX_PASSES;
     const uint32_t nt = f.n_tiles;
@@ -379,13 +391,6 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
         if (!c->sorted_pts) HIP_TRY(c, hipMalloc(&c->sorted_pts, static_cast<size_t>(c->cap_padded) * 16));
         if (!c->rows) HIP_TRY(c, hipMalloc(&c->rows, static_cast<size_t>(CM_ROW_TABLE_CAP) * 8));
         if (!c->d_state_o) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_state_o), sizeof(CmFrameState)));
-        uint32_t kb_o = 0;
-        int gm_o = 0;
-        if (f.crop_enable) {
-            if (!box_grid(p->crop_min, p->crop_max, f.inv_cell, &kb_o))
-                return fail(c, CM_CAPACITY, "outlier radius too small for the crop box (radius grid exceeds 32 bits)");
-            gm_o = 1;
-        }
         const uint32_t passes_o = gm_o ? (kb_o + CM_RADIX_BITS - 1) / CM_RADIX_BITS : CM_MAX_PASSES;
         HIP_TRY(c, hipMemsetAsync(c->d_state_o, 0, sizeof(CmFrameState), st));
         HIP_TRY(c, hipMemsetAsync(c->mask, 0, f.n_padded, st));

@@ -101,7 +101,7 @@ typedef struct cm_result {
     float device_ms;               /* first kernel start -> last kernel end (CM_FLAG_PROFILE) */
 } cm_result;
 
-#define CM_MAX_STAGES 32
+#define CM_MAX_STAGES 48
 typedef struct cm_stage_times {
     uint32_t n_stages;
     uint32_t _pad;

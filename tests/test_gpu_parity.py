@@ -407,12 +407,30 @@ def test_outlier_radius_too_small_is_an_error():
     params.outlier_radius = 1e-5
     with capi.CloudMerger(max_points_total=20_000, max_sensors=4) as cm:
         cm.submit_all(sensors)
-        with pytest.raises(capi.CloudMergeError) as e:
-            cm.merge_voxelize(params)
+        with pytest.raises(capi.CloudMergeError) as e:    # no crop box: found on the device, from the data's extent;
+            cm.merge_voxelize(params)                     # the frame was fused and is gone, like a PCL error print
         assert e.value.status == capi.CAPACITY
         params.outlier_radius = None                      # the context stays usable
         cm.submit_all(sensors)
         assert cm.merge_voxelize(params).status == capi.OK
+
+
+def test_rejected_arguments_do_not_consume_the_frame():
+    sensors, params = synth.config2(n_per_sensor=5_000)
+    n_in = sum(s.n for s in sensors)
+    with capi.CloudMerger(max_points_total=20_000, max_sensors=4) as cm:
+        cm.submit_all(sensors)
+        bad = MergeParams(leaf=params.leaf, crop_min=(-50, -50, -5), crop_max=(50, 50, 5), outlier_radius=1e-5)
+        with pytest.raises(capi.CloudMergeError) as e:    # crop box + radius: rejected on the host, before the fuse
+            cm.merge_voxelize(bad)
+        assert e.value.status == capi.CAPACITY
+        bad = MergeParams(leaf=(0.0, 0.1, 0.1))
+        with pytest.raises(capi.CloudMergeError) as e:
+            cm.merge_voxelize(bad)
+        assert e.value.status == capi.BAD_ARG
+        res = cm.merge_voxelize(params)                   # no re-submit: the clouds are still fresh
+        assert res.status == capi.OK and res.n_in == n_in
+        assert cm.merge_voxelize(params).status == capi.NOT_READY   # ... and the accepted call consumed them
 
 
 def test_concurrent_ingest_threads_and_consumer():
