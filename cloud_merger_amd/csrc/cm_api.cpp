@@ -89,6 +89,23 @@ struct cm_ctx {
     bool have_result = false;
     bool out_is_merged = false;
 
+    // bucket path (cm_kernels_v2.hip)
+    int path_mode = 0;                   // CM_PATH: 0 auto (bucket path when it applies), 1 classic only, 2 bucket only where it applies
+    void *rec_a = nullptr, *rec_b = nullptr;      // 16-byte point records, ping-pong
+    unsigned char* dig = nullptr;        // next digit of every record
+    unsigned long long* tile_state = nullptr;     // published kept-voxel counts of the local finish
+    float* records = nullptr;            // min/max/count per tile
+    bool pred_ok = false;                // a box predicted from an earlier frame's bounds
+    float pred_min[3] = {0, 0, 0}, pred_max[3] = {0, 0, 0};
+    uint32_t v2_extra_passes = 0;        // buckets overflowed LDS: sort more bits globally
+    uint32_t v2_off_frames = 0;          // ... or give the path a rest
+    bool last_v2 = false, last_predicted = false;
+    cm_params last_params;
+    int last_grid_mode = 0;
+    uint32_t last_key_bits = 0;
+    int cell_min_b[3] = {0, 0, 0}, cell_div_b[3] = {1, 1, 1};   // grid the cells in out_key are relative to
+    uint64_t n_redone = 0;               // frames the bucket path handed back to the classic one
+
     std::vector<hipEvent_t> prof_ev;
     std::vector<std::string> prof_names;
     size_t prof_used = 0;
@@ -182,6 +199,7 @@ void free_all(cm_ctx* c) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(c->keys_a); F(c->keys_b); F(c->vals_a); F(c->vals_b); F(c->hist); F(c->totals);
     F(c->seg_counts); F(c->seg_tile_counts); F(c->seg_groups); F(c->grp); F(c->partials); F(c->out_key); F(c->out_cnt); F(c->merged_total); F(c->out); F(c->merged); F(c->partial); F(c->table_entries); F(c->mask); F(c->sorted_pts); F(c->rows); F(c->d_state_o);
+    F(c->rec_a); F(c->rec_b); F(c->dig); F(c->tile_state); F(c->records);
     F(c->d_frame); F(c->d_state[0]); F(c->d_state[1]);
     if (c->h_state) (void)hipHostFree(c->h_state);
     for (auto& s : c->slots) {
@@ -231,7 +249,8 @@ int set_slot_cloud(cm_ctx* c, uint32_t sensor, const void* data, bool on_device,
 }
 
 // Builds the frame descriptor and enqueues every kernel of the frame on c->stream.
-int build_frame(cm_ctx* c, const cm_params* p, bool consume, std::vector<std::unique_lock<std::mutex>>& locks) {
+int build_frame(cm_ctx* c, const cm_params* p, bool consume, std::vector<std::unique_lock<std::mutex>>& locks,
+                bool gate = true) {
     for (uint32_t s = 0; s < c->max_sensors; ++s) locks.emplace_back(c->slots[s].mu);
 
     // Frame assembly policy (pc_preprocessing_main.cpp:134-157).
@@ -241,7 +260,7 @@ int build_frame(cm_ctx* c, const cm_params* p, bool consume, std::vector<std::un
         if (c->slots[s].fresh) fresh |= 1u << s;
     }
     const uint32_t required = p->required_sensor_mask ? p->required_sensor_mask : have;
-    if (have == 0 || (required & ~fresh) != 0) return CM_NOT_READY;
+    if (have == 0 || (gate && (required & ~fresh) != 0)) return CM_NOT_READY;   // gate off: redoing a fused frame
 
     CmFrameDev& f = c->frame;
     std::memset(&f, 0, sizeof f);
@@ -279,6 +298,127 @@ int build_frame(cm_ctx* c, const cm_params* p, bool consume, std::vector<std::un
     c->n_sensors_used = k;
     if (consume)
         for (auto& sl : c->slots) sl.fresh = false;   // flag reset, :151-157
+    return CM_OK;
+}
+
+int launch_classic(cm_ctx* c, const cm_params* p, int mode, int grid_mode, uint32_t key_bits, bool outl, int gm_o,
+                   uint32_t kb_o);
+
+// Bounds of the merged cloud by one k_minmax pass and a host round trip: only when the bucket path
+// has no box yet (first frame of a context without a crop box, or after a point left the predicted box).
+void set_predicted_box(cm_ctx* c, const float mn[3], const float mx[3], const float leaf[3]) {
+    for (int a = 0; a < 3; ++a) {
+        const float ext = mx[a] - mn[a];
+        const float margin = std::max(ext / 8.0f, 8.0f * leaf[a]);
+        c->pred_min[a] = mn[a] - margin;
+        c->pred_max[a] = mx[a] + margin;
+    }
+    c->pred_ok = true;
+}
+
+// Keeps the predicted box while the cloud stays comfortably inside it and the box is not wastefully
+// large (so the frame descriptor, and with it the key width, stays put from frame to frame).
+void update_predicted_box(cm_ctx* c, const float mn[3], const float mx[3], const float leaf[3]) {
+    bool redo = !c->pred_ok;
+    for (int a = 0; a < 3 && !redo; ++a) {
+        const float margin = std::max((mx[a] - mn[a]) / 8.0f, 8.0f * leaf[a]);
+        const float lo = mn[a] - c->pred_min[a], hi = c->pred_max[a] - mx[a];
+        redo = !(lo >= margin / 4.0f && lo <= 3.0f * margin && hi >= margin / 4.0f && hi <= 3.0f * margin);
+    }
+    if (redo) set_predicted_box(c, mn, mx, leaf);
+}
+
+int bootstrap_box(cm_ctx* c) {
+    const CmFrameDev& f = c->frame;
+    hipStream_t st = c->stream;
+    if (!c->frame_uploaded_valid || std::memcmp(&f, &c->frame_uploaded, sizeof f) != 0) {
+        cmk_setup(st, f, c->d_frame);
+        c->frame_uploaded = f;
+        c->frame_uploaded_valid = true;
+    }
+    const uint32_t n_partials = f.n_tiles < CM_MINMAX_BLOCKS ? f.n_tiles : CM_MINMAX_BLOCKS;
+    cmk_minmax(st, c->d_frame, c->partials, n_partials, nullptr);
+    std::vector<float> rec(static_cast<size_t>(n_partials) * 8);
+    HIP_TRY(c, hipMemcpyAsync(rec.data(), c->partials, rec.size() * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    const float inf = std::numeric_limits<float>::infinity();
+    float mn[3] = {inf, inf, inf}, mx[3] = {-inf, -inf, -inf};
+    uint64_t cnt = 0;
+    for (uint32_t r = 0; r < n_partials; ++r) {
+        uint32_t k;
+        std::memcpy(&k, &rec[r * 8 + 6], 4);
+        if (!k) continue;
+        cnt += k;
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = std::min(mn[a], rec[r * 8 + a]);
+            mx[a] = std::max(mx[a], rec[r * 8 + 3 + a]);
+        }
+    }
+    c->pred_ok = false;
+    if (cnt) {
+        float leaf[3];
+        for (int a = 0; a < 3; ++a) leaf[a] = 1.0f / f.inv_leaf[a];
+        set_predicted_box(c, mn, mx, leaf);
+    }
+    return CM_OK;
+}
+
+// The launch sequence of cm_kernels_v2.hip for the frame in c->frame: n_global 8-bit passes over the
+// key bits above `low_bits`, then the local finish.
+int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits) {
+    CmFrameDev& f = c->frame;
+    hipStream_t st = c->stream;
+    const size_t npad = c->cap_padded;
+    if (!c->rec_a) HIP_TRY(c, hipMalloc(&c->rec_a, npad * 16));
+    if (!c->rec_b) HIP_TRY(c, hipMalloc(&c->rec_b, npad * 16));
+    if (!c->dig) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->dig), npad));
+    if (!c->tile_state) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->tile_state), (npad / CM2_LT + 1) * 8));
+    if (!c->records) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->records), static_cast<size_t>(c->cap_tiles) * 32));
+    if (!c->frame_uploaded_valid || std::memcmp(&f, &c->frame_uploaded, sizeof f) != 0) {
+        prof_mark(c, "k_setup");
+        cmk_setup(st, f, c->d_frame);
+        c->frame_uploaded = f;
+        c->frame_uploaded_valid = true;
+    }
+    CmFrameState* state = c->d_state[c->cur];
+    CmFrameState* state_next = c->d_state[c->cur ^ 1];
+    c->from_crop = grid_mode == 1;
+    c->last_v2 = true;
+    c->last_predicted = grid_mode == 2;
+    const uint32_t nt = f.n_tiles;
+    const uint32_t n_groups = (nt + CM_GROUP - 1) / CM_GROUP;
+    const uint32_t gw = n_groups * CM_RADIX;
+    const size_t gstride = static_cast<size_t>(c->cap_groups) * CM_RADIX;
+    const bool big = n_groups > CM_DIRECT_GROUPS;
+    uint32_t* grp0 = c->grp + gstride * (c->frame_seq & 1u);
+    uint32_t* grp0_next = c->grp + gstride * ((c->frame_seq & 1u) ^ 1u);
+    ++c->frame_seq;
+    c->h_state->err = 0;                               // error words are written straight into the host record
+    c->frame_mask = nullptr;
+    prof_mark(c, "k2_hist0");
+    cmk2_hist0(st, c->d_frame, state, c->hist, grp0, grp0_next, c->grp + 2 * gstride, gw, static_cast<uint32_t>(gstride),
+               c->tile_state, nt + 1, c->records, grid_mode, low_bits, n_global, nt);
+    for (uint32_t pass = 0; pass < n_global; ++pass) {
+        uint32_t* grp = pass == 0 ? grp0 : c->grp + 2 * gstride + static_cast<size_t>(pass - 1) * gw;
+        if (pass > 0) { prof_mark(c, "k2_hist"); cmk2_hist(st, state, c->dig, c->hist, grp, nt); }
+        if (big) { prof_mark(c, "k_gscan"); cmk_gscan(st, state, grp, c->totals, pass, n_groups); }
+        prof_mark(c, "k2_scatter");
+        const void* in = (pass & 1u) ? c->rec_a : c->rec_b;
+        void* out = (pass & 1u) ? c->rec_b : c->rec_a;
+        cmk2_scatter(st, pass == 0, c->d_frame, state, in, out, c->dig, c->hist, grp, big ? c->totals : nullptr,
+                     low_bits + 8 * pass, pass + 1 < n_global ? low_bits + 8 * (pass + 1) : 32u, nt, n_groups,
+                     f.n_padded, c->records, nt, grid_mode == 2 ? 1 : 0);
+    }
+    prof_mark(c, "k2_local");
+    cmk2_local(st, c->d_frame, state, state_next, c->h_state_dev, ((n_global - 1) & 1u) ? c->rec_b : c->rec_a,
+               c->tile_state, c->out, c->out_key, c->out_cnt, low_bits, nt);
+    prof_mark(c, "end");
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev_done, st));
+    c->cur ^= 1;
+    c->in_flight.store(true);
+    c->pending = true;
+    c->pending_trivial = false;
     return CM_OK;
 }
 
@@ -335,6 +475,47 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
         return CM_OK;
     }
 
+    c->last_params = *p;
+    c->last_grid_mode = grid_mode;
+    c->last_key_bits = key_bits;
+    c->last_v2 = false;
+    c->last_predicted = false;
+
+    // Bucket path: centroids of one GPU's whole frame, with a box known before the first point is
+    // read — the crop box, or the last frame's bounds plus a margin (verified on the device).
+    bool want_v2 = c->path_mode != 1 && mode == 0 && !outl && c->lds_rank;
+    if (want_v2 && c->v2_off_frames) { --c->v2_off_frames; want_v2 = false; }
+    if (want_v2) {
+        int gm = grid_mode;
+        uint32_t kb = key_bits;
+        if (gm == 0) {
+            if (!c->pred_ok) {
+                const int e = bootstrap_box(c);
+                if (e < 0) return e;
+            }
+            if (c->pred_ok && box_grid(c->pred_min, c->pred_max, inv_leaf, &kb)) {
+                gm = 2;
+                for (int a = 0; a < 3; ++a) { f.ext_min[a] = c->pred_min[a]; f.ext_max[a] = c->pred_max[a]; }
+            } else {
+                c->pred_ok = false;
+            }
+        }
+        if (gm != 0) {
+            uint32_t g = 1 + (kb > CM2_MAX_LOW_BITS + 8 ? (kb - CM2_MAX_LOW_BITS - 1) / 8 : 0) + c->v2_extra_passes;
+            if (g > 1 && 8 * (g - 1) >= kb) g = 0;           // nothing left for the local finish to add
+            if (g >= 1 && g <= CM_MAX_PASSES) {
+                const uint32_t low = kb > 8 * g ? kb - 8 * g : 0;
+                return launch_bucket(c, gm, g, low);
+            }
+        }
+    }
+    return launch_classic(c, p, mode, grid_mode, key_bits, outl, gm_o, kb_o);
+}
+
+// The launch sequence of cm_kernels.hip for the frame in c->frame.
+int launch_classic(cm_ctx* c, const cm_params* p, int mode, int grid_mode, uint32_t key_bits, bool outl, int gm_o,
+                   uint32_t kb_o) {
+    CmFrameDev& f = c->frame;
     hipStream_t st = c->stream;
     if (!c->frame_uploaded_valid || std::memcmp(&f, &c->frame_uploaded, sizeof f) != 0) {
         prof_mark(c, "k_setup");
@@ -435,10 +616,41 @@ int wait_frame(cm_ctx* c, cm_result* res) {
     } else {
         HIP_TRY(c, hipEventSynchronize(c->ev_done));
         c->in_flight.store(false);
+        if (c->last_v2) {
+            // The bucket path hands a frame back when a point lay outside the predicted box, when a
+            // bucket did not fit LDS, or when a workgroup gave up waiting for its predecessors: the
+            // classic path redoes it (the sensors' clouds are still in place) and the cause is dealt with.
+            const CmFrameState& h0 = *c->h_state;
+            if (h0.outside || h0.err == CM_DEV_ERR_BUCKET || h0.err == CM_DEV_ERR_LOOKBACK) {
+                if (h0.outside) c->pred_ok = false;
+                if (h0.err == CM_DEV_ERR_BUCKET && c->v2_extra_passes < CM_MAX_PASSES) ++c->v2_extra_passes;
+                if (h0.err == CM_DEV_ERR_LOOKBACK) c->v2_off_frames = 0xFFFFFFFFu;
+                ++c->n_redone;
+                c->prof_used = 0;
+                c->last_v2 = false;
+                c->last_predicted = false;
+                {
+                    // Re-assemble from the slots (a sensor may have delivered a newer cloud meanwhile: whole
+                    // clouds only, never a torn one) and hold them until the kernels are enqueued, as enqueue does.
+                    std::vector<std::unique_lock<std::mutex>> locks;
+                    const cm_params pr = c->last_params;
+                    int e = build_frame(c, &pr, false, locks, false);
+                    if (e == CM_OK && c->frame.n_padded)
+                        e = launch_classic(c, &pr, 0, c->last_grid_mode, c->last_key_bits, false, 0, 0);
+                    else if (e == CM_OK)
+                        e = CM_NOT_READY;
+                    if (e != CM_OK) { c->pending = false; return e == CM_NOT_READY ? fail(c, CM_INTERNAL, "frame could not be redone: its clouds were cleared") : e; }
+                }
+                HIP_TRY(c, hipEventSynchronize(c->ev_done));
+                c->in_flight.store(false);
+                r.n_sensors = c->n_sensors_used;
+                r.n_in = c->n_in;
+            }
+        }
         const CmFrameState& h = *c->h_state;
         if (h.err) {
             c->pending = false;
-            if (h.err == 2 && c->lds_rank) {
+            if (h.err == CM_DEV_ERR_UNSORTED && c->lds_rank) {
                 // The sorted keys were not sorted: stop trusting lane-ordered LDS adds on this device.
                 c->lds_rank = false;
                 return fail(c, CM_INTERNAL, "radix sort check failed with LDS-add ranking; switched to ballot ranking, resubmit the frame");
@@ -454,10 +666,32 @@ int wait_frame(cm_ctx* c, cm_result* res) {
         for (int a = 0; a < 3; ++a) {
             r.min_b[a] = h.min_b[a]; r.max_b[a] = h.max_b[a]; r.div_b[a] = h.div_b[a];
             r.min_p[a] = h.min_p[a]; r.max_p[a] = h.max_p[a];
+            c->cell_min_b[a] = h.min_b[a]; c->cell_div_b[a] = h.div_b[a];
         }
         r.key_bits = h.key_bits;
         r.sort_passes = h.n_passes;
-        r.path_flags = c->lds_rank ? 1u : 0u;
+        r.path_flags = (c->lds_rank ? 1u : 0u) | (c->last_v2 ? 2u : 0u) | (c->last_predicted ? 4u : 0u);
+        if (c->last_predicted && h.status == CM_OK) {
+            // The device sorted by cells of the predicted box (same order); the grid PCL itself would
+            // report comes from the cloud's exact bounds, which the frame also produced (A.4 steps 2, 4).
+            unsigned long long cells = 1;
+            for (int a = 0; a < 3; ++a) {
+                const float lo = h.min_p[a] * c->frame.inv_leaf[a], hi = h.max_p[a] * c->frame.inv_leaf[a];
+                r.min_b[a] = static_cast<int32_t>(std::floor(lo));
+                r.max_b[a] = static_cast<int32_t>(std::floor(hi));
+                r.div_b[a] = r.max_b[a] - r.min_b[a] + 1;
+                cells *= static_cast<unsigned long long>(r.div_b[a]);
+            }
+            uint32_t bits = 1;
+            while (bits < 32 && (cells - 1) >> bits) ++bits;
+            r.key_bits = bits;
+        }
+        if (h.status == CM_OK && c->last_mode == 0 && !c->frame_mask &&
+            (c->last_predicted || (!c->last_v2 && c->last_grid_mode == 0))) {
+            float leaf[3];
+            for (int a = 0; a < 3; ++a) leaf[a] = 1.0f / c->frame.inv_leaf[a];
+            update_predicted_box(c, h.min_p, h.max_p, leaf);
+        }
         if (h.status == CM_OK) {
             r.n_merged = h.n_valid;
             r.n_out = h.n_out;
@@ -559,6 +793,7 @@ int cm_create(cm_ctx** out, int device, const cm_limits* lim) {
     ok = ok && hipMemset(c->d_state[0], 0, sizeof(CmFrameState)) == hipSuccess;
     ok = ok && hipMemset(c->d_state[1], 0, sizeof(CmFrameState)) == hipSuccess;
     ok = ok && hipDeviceSynchronize() == hipSuccess;
+    if (const char* pm = getenv("CM_PATH")) c->path_mode = std::strcmp(pm, "classic") == 0 ? 1 : 0;
     if (ok) {
         // Probe the device once: lane-ordered returning LDS adds allow the cheap stable ranking.
         // CM_LDS_RANK=0 forces the ballot-match ranking, CM_LDS_RANK=1 skips the probe.
@@ -728,13 +963,14 @@ int cm_result_copy_cells(cm_ctx* c, int32_t* ijk, uint32_t* counts, uint64_t cap
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (ijk) {
-        const cm_result& r = c->result;
-        const uint32_t d0 = static_cast<uint32_t>(r.div_b[0]), d1 = static_cast<uint32_t>(r.div_b[1]);
+        // out_key holds linear indices in the grid the frame was sorted in (the crop box, the predicted
+        // box or the cloud's own bounds); the caller gets absolute cells floor(p / leaf).
+        const uint32_t d0 = static_cast<uint32_t>(c->cell_div_b[0]), d1 = static_cast<uint32_t>(c->cell_div_b[1]);
         for (uint64_t i = 0; i < n; ++i) {
             const uint32_t k = keys[i];
-            ijk[3 * i + 0] = static_cast<int32_t>(k % d0) + r.min_b[0];
-            ijk[3 * i + 1] = static_cast<int32_t>((k / d0) % d1) + r.min_b[1];
-            ijk[3 * i + 2] = static_cast<int32_t>(k / (d0 * d1)) + r.min_b[2];
+            ijk[3 * i + 0] = static_cast<int32_t>(k % d0) + c->cell_min_b[0];
+            ijk[3 * i + 1] = static_cast<int32_t>((k / d0) % d1) + c->cell_min_b[1];
+            ijk[3 * i + 2] = static_cast<int32_t>(k / (d0 * d1)) + c->cell_min_b[2];
         }
     }
     return CM_OK;

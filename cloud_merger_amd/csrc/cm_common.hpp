@@ -1,0 +1,257 @@
+// cm_common.hpp — device helpers shared by the kernel files (cm_kernels.hip, cm_kernels_v2.hip):
+// point loaders, the reference's fp32 transform / crop arithmetic, PCL's grid set-up, workgroup scans,
+// the centroid accumulator and the frame-state report. Semantics in SURVEY.md Appendix A.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "cm_device.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+struct Pt { float x, y, z, i; };
+
+__device__ __forceinline__ float load_f32_unaligned(const unsigned char* p) {
+    float f;
+    __builtin_memcpy(&f, p, 4);
+    return f;
+}
+
+__device__ __forceinline__ Pt load_point(const unsigned char* __restrict__ data, uint32_t layout,
+                                         uint32_t step, uint32_t ox, uint32_t oy, uint32_t oz,
+                                         uint32_t oi, uint32_t idx) {
+    Pt p;
+    if (layout == CM_LAYOUT_XYZI16) {
+        const float4 v = *reinterpret_cast<const float4*>(data + static_cast<size_t>(idx) * 16);
+        p.x = v.x; p.y = v.y; p.z = v.z; p.i = v.w;
+    } else if (layout == CM_LAYOUT_PCL32) {
+        const unsigned char* q = data + static_cast<size_t>(idx) * 32;
+        const float4 v = *reinterpret_cast<const float4*>(q);
+        p.x = v.x; p.y = v.y; p.z = v.z;
+        p.i = *reinterpret_cast<const float*>(q + 16);
+    } else {
+        const unsigned char* q = data + static_cast<size_t>(idx) * step;
+        p.x = load_f32_unaligned(q + ox);
+        p.y = load_f32_unaligned(q + oy);
+        p.z = load_f32_unaligned(q + oz);
+        p.i = (oi == 0xFFFFFFFFu) ? 0.0f : load_f32_unaligned(q + oi);
+    }
+    return p;
+}
+
+// pcl::transformPointCloud scalar form: ((m0*x + m1*y) + m2*z) + m3, each op rounded (A.1).
+__device__ __forceinline__ float xf_row(float m0, float m1, float m2, float m3, float x, float y, float z) {
+    return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(m0, x), __fmul_rn(m1, y)), __fmul_rn(m2, z)), m3);
+}
+
+__device__ __forceinline__ bool finite_f32(float v) {
+    return (__float_as_uint(v) & 0x7F800000u) != 0x7F800000u;
+}
+
+// PassThrough x3 (closed box) + "non-finite points vanish" (A.2, A.3).
+__device__ __forceinline__ bool point_valid(float x, float y, float z, uint32_t crop,
+                                            const float* __restrict__ cmin, const float* __restrict__ cmax) {
+    bool ok = finite_f32(x) && finite_f32(y) && finite_f32(z);
+    if (crop) {
+        ok = ok && !(x < cmin[0] || x > cmax[0]) && !(y < cmin[1] || y > cmax[1]) &&
+             !(z < cmin[2] || z > cmax[2]);
+    }
+    return ok;
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// Exclusive scan over the 256 threads of a workgroup. lds: CM_WAVES words. Ends with a barrier.
+__device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* lds, uint32_t* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan_u32(v, lane);
+    if (lane == 63) lds[w] = incl;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < CM_WAVES; ++k) {
+        const uint32_t c = lds[k];
+        if (k < w) woff += c;
+        tot += c;
+    }
+    __syncthreads();
+    *total = tot;
+    return woff + incl - v;
+}
+
+__device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t* lds) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t tot = 0;
+#pragma unroll
+    for (int k = 0; k < CM_WAVES; ++k) tot += lds[k];
+    __syncthreads();
+    return tot;
+}
+
+// Which sensor owns padded tile `tile` (wave-uniform).
+__device__ __forceinline__ uint32_t sensor_of_tile(const CmFrameDev* __restrict__ fd, uint32_t tile) {
+    const uint32_t first = tile * CM_TILE;
+    uint32_t s = 0;
+    for (uint32_t q = 1; q < fd->n_sensors; ++q) s += (first >= fd->s[q].base) ? 1u : 0u;
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tile loader: the 16 points a thread owns in its tile (wave-striped), every load issued before
+// the first use. Slots past the end of the cloud read as NaN and are never valid.
+// ------------------------------------------------------------------------------------------------
+template <int LAYOUT, int N>
+__device__ __forceinline__ void load_tile_points(const CmSensorDev& sd, uint32_t first, Pt (&p)[N]) {
+    const unsigned char* __restrict__ data = sd.data;
+    const uint32_t n = sd.n, step = sd.point_step;
+    const uint32_t ox = sd.off_x, oy = sd.off_y, oz = sd.off_z, oi = sd.off_i;
+    const float nan = __uint_as_float(0x7FC00000u);
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        const uint32_t i = first + r * 64;
+        if (i < n) {
+            p[r] = load_point(data, LAYOUT, step, ox, oy, oz, oi, i);
+        } else {
+            p[r].x = nan; p[r].y = nan; p[r].z = nan; p[r].i = 0.f;
+        }
+    }
+}
+
+// N points of one lane, 64 apart (wave-striped), starting at index `first` of the sensor's cloud.
+template <int N>
+__device__ __forceinline__ void load_tile(const CmSensorDev& sd, uint32_t first, Pt (&p)[N]) {
+    if (sd.layout == CM_LAYOUT_XYZI16) load_tile_points<CM_LAYOUT_XYZI16, N>(sd, first, p);
+    else if (sd.layout == CM_LAYOUT_PCL32) load_tile_points<CM_LAYOUT_PCL32, N>(sd, first, p);
+    else load_tile_points<CM_LAYOUT_GENERIC, N>(sd, first, p);
+}
+
+struct Grid {
+    int status;
+    uint32_t n_valid_k0;
+    float min_p[3], max_p[3];
+    int min_b[3], max_b[3], div_b[3];
+    uint32_t key_bits, n_passes;
+};
+
+__device__ __forceinline__ void compute_grid(const CmFrameDev* __restrict__ fd,
+                                             const float* __restrict__ partials, uint32_t n_partials,
+                                             int from_crop, const float* __restrict__ inv, float (*s_red)[8], Grid& g) {
+    g.status = CM_DEV_OK;
+    g.key_bits = 0; g.n_passes = 0; g.n_valid_k0 = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { g.min_b[a] = 0; g.max_b[a] = 0; g.div_b[a] = 1; g.min_p[a] = 0.f; g.max_p[a] = 0.f; }
+    if (from_crop == 2) {                               // bounds of the whole fused cloud, from the host
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { g.min_p[a] = fd->ext_min[a]; g.max_p[a] = fd->ext_max[a]; }
+    } else if (from_crop) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { g.min_p[a] = fd->crop_min[a]; g.max_p[a] = fd->crop_max[a]; }
+    } else {
+        // getMinMax3D: fold the per-workgroup records of k_minmax (min/max are exact and
+        // order-independent, so every workgroup gets the same answer).
+        const float inf = __uint_as_float(0x7F800000u);
+        float v[6] = {inf, inf, inf, -inf, -inf, -inf};
+        uint32_t cnt = 0;
+        for (uint32_t r = threadIdx.x; r < n_partials; r += CM_BLOCK) {
+            const float4 lo = *reinterpret_cast<const float4*>(partials + r * 8);
+            const float4 hi = *reinterpret_cast<const float4*>(partials + r * 8 + 4);
+            v[0] = fminf(v[0], lo.x); v[1] = fminf(v[1], lo.y); v[2] = fminf(v[2], lo.z);
+            v[3] = fmaxf(v[3], lo.w); v[4] = fmaxf(v[4], hi.x); v[5] = fmaxf(v[5], hi.y);
+            cnt += __float_as_uint(hi.z);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[k] = fminf(v[k], __shfl_xor(v[k], d));
+#pragma unroll
+            for (int k = 3; k < 6; ++k) v[k] = fmaxf(v[k], __shfl_xor(v[k], d));
+            cnt += __shfl_xor(cnt, d);
+        }
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s_red[w][k] = v[k];
+            s_red[w][6] = __uint_as_float(cnt);
+        }
+        __syncthreads();
+        cnt = 0;
+#pragma unroll
+        for (int q = 0; q < CM_WAVES; ++q) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[k] = (q == 0) ? s_red[0][k] : fminf(v[k], s_red[q][k]);
+#pragma unroll
+            for (int k = 3; k < 6; ++k) v[k] = (q == 0) ? s_red[0][k] : fmaxf(v[k], s_red[q][k]);
+            cnt += __float_as_uint(s_red[q][6]);
+        }
+        g.n_valid_k0 = cnt;
+        if (cnt == 0) { g.status = CM_DEV_EMPTY; return; }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { g.min_p[a] = v[a]; g.max_p[a] = v[3 + a]; }
+    }
+    long long d[3];
+    bool overflow = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float ext = __fmul_rn(__fsub_rn(g.max_p[a], g.min_p[a]), inv[a]);
+        if (!(ext < 2147483648.0f)) { overflow = true; d[a] = 0; }
+        else d[a] = static_cast<long long>(ext) + 1;       // truncation toward zero
+    }
+    if (!overflow && d[0] * d[1] * d[2] > 2147483647LL) overflow = true;
+    if (overflow) { g.status = CM_DEV_OVERFLOW; return; }
+    unsigned long long cells = 1;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int lo = static_cast<int>(floorf(__fmul_rn(g.min_p[a], inv[a])));
+        const int hi = static_cast<int>(floorf(__fmul_rn(g.max_p[a], inv[a])));
+        g.min_b[a] = lo; g.max_b[a] = hi; g.div_b[a] = hi - lo + 1;
+        cells *= static_cast<unsigned long long>(hi - lo + 1);
+    }
+    // div_b can exceed the guard's dx by one per axis; the 32-bit key still has to hold it.
+    if (cells > 0xFFFFFFFFull) { g.status = CM_DEV_OVERFLOW; return; }
+    uint32_t bits = 1;
+    while (bits < 32 && (cells - 1) >> bits) ++bits;
+    g.key_bits = bits;
+    g.n_passes = (bits + CM_RADIX_BITS - 1) / CM_RADIX_BITS;
+}
+
+struct Acc { float x, y, z, i; uint32_t c; };
+
+__device__ __forceinline__ void acc_add(Acc& a, const Acc& b) {
+    a.x = __fadd_rn(a.x, b.x); a.y = __fadd_rn(a.y, b.y);
+    a.z = __fadd_rn(a.z, b.z); a.i = __fadd_rn(a.i, b.i);
+    a.c += b.c;
+}
+__device__ __forceinline__ Acc acc_shfl_down(const Acc& a, int d) {
+    Acc r;
+    r.x = __shfl_down(a.x, d); r.y = __shfl_down(a.y, d); r.z = __shfl_down(a.z, d);
+    r.i = __shfl_down(a.i, d); r.c = __shfl_down(a.c, d);
+    return r;
+}
+
+// The workgroup that knows the frame's final numbers writes the whole state record straight into
+// pinned host memory (visible to the host when the kernel completes): no copy after the frame.
+__device__ __forceinline__ void report_state(uint32_t* __restrict__ host, const CmFrameState* __restrict__ st,
+                                             int status, uint32_t n_out, bool skip_err = false) {
+    if (threadIdx.x < sizeof(CmFrameState) / 4 && !(skip_err && threadIdx.x == offsetof(CmFrameState, err) / 4)) {
+        uint32_t wv = reinterpret_cast<const uint32_t*>(st)[threadIdx.x];
+        if (threadIdx.x == offsetof(CmFrameState, status) / 4) wv = static_cast<uint32_t>(status);
+        if (threadIdx.x == offsetof(CmFrameState, n_out) / 4) wv = n_out;
+        host[threadIdx.x] = wv;
+    }
+}
+
+}  // namespace

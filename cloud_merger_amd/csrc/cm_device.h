@@ -25,6 +25,19 @@
 #define CM_SEG_GROUP 256      // sorted tiles per kept-voxel group total (== CM_BLOCK)
 #define CM_SEG_DIRECT_TILES 4096  // up to this many sorted tiles the per-tile counts are summed directly
 
+// Bucket path (cm_kernels_v2.hip): G global 8-bit passes over 16-byte point records on the HIGH key
+// bits, then one workgroup-local finish (LDS sort of the low bits + centroids) per bucket-aligned tile.
+#define CM2_BLOCK 512         // threads per workgroup in the record passes (8 wave64, 8 points each)
+#define CM2_WAVES 8
+#define CM2_ITEMS 8
+#define CM2_LBLOCK 1024       // threads per workgroup in the local finish (16 wave64)
+#define CM2_LWAVES 16
+#define CM2_LT 4096           // nominal records per local tile
+#define CM2_LCAP 6144         // LDS capacity in records: a tile owns the buckets that START in it, so it
+                              // can run past its nominal end by one bucket tail (<= CM2_LCAP - CM2_LT)
+#define CM2_LITEMS 6          // CM2_LCAP / CM2_LBLOCK
+#define CM2_MAX_LOW_BITS 14   // key bits left to the local finish when the global passes allow it
+
 // Point layouts the loaders special-case.
 #define CM_LAYOUT_XYZI16 0    // x,y,z,intensity @0,4,8,12, step 16, 16-B aligned: one dwordx4 load
 #define CM_LAYOUT_PCL32 1     // pcl::PointXYZI image, step 32, intensity @16: dwordx4 + dword
@@ -60,7 +73,8 @@ struct CmFrameDev {
 
 // Per-frame device state, zeroed before the first kernel of a frame.
 struct CmFrameState {
-    uint32_t _unused[6];
+    uint32_t outside;         // bucket path: a point fell outside the predicted box (frame must be redone)
+    uint32_t _unused[5];
     uint32_t n_valid_k0;      // valid points counted by the min/max pass
     int32_t status;           // cm_status of the frame (0 OK, 1 EMPTY, 2 OVERFLOW)
     int32_t min_b[3], max_b[3], div_b[3];
@@ -77,6 +91,9 @@ struct CmFrameState {
 #define CM_DEV_OK 0
 #define CM_DEV_EMPTY 1
 #define CM_DEV_OVERFLOW 2
+#define CM_DEV_ERR_UNSORTED 2u   // CmFrameState.err: the radix sort's output was not sorted
+#define CM_DEV_ERR_LOOKBACK 3u   // ... a workgroup waited too long for its predecessors' counts
+#define CM_DEV_ERR_BUCKET 4u     // ... a bucket did not fit the local finish's LDS capacity
 #define CM_DEV_OUTLIER_GRID 3   // the radius grid of the outlier stage does not fit (rows or 32-bit index)
 
 #define CM_ROW_TABLE_CAP (1u << 22)   // rows (y,z cell pairs) of the outlier stage's candidate grid

@@ -1,0 +1,824 @@
+// cm_kernels_v2.hip — the "bucket" path of merge -> voxel grid for gfx950: same results as
+// cm_kernels.hip, about half its HBM traffic.
+//
+// cm_kernels.hip sorts (voxel key, point index) pairs by the whole key (4 passes for a 30-bit grid)
+// and then gathers every point again through its index (a 128-byte line per 16-byte point). Here the
+// 16-byte transformed point itself is what moves, and only as far as it has to:
+//   k2_hist0     transform + crop + key of every raw point, counts of the first HIGH digit per tile;
+//                min/max records of the cloud (for the next frame's box)        [16 B/pt read]
+//   k2_scatter<1> raw points -> records (x,y,z,intensity in the target frame), stable scatter by that
+//                digit, next digit of every record as one byte                  [16 B r, 17 B w]
+//   k2_hist      counts of the next digit per tile, from the bytes              [1 B/pt read]
+//   k2_scatter<0> records -> records by the next digit                          [16 B r, 16 B w]
+//   k2_local     the records are now grouped by the high key bits ("buckets"). One workgroup takes the
+//                buckets that start in its 4096-record tile, sorts them by the remaining low bits
+//                inside LDS, reduces the runs to centroids (PCL's order: ascending voxel index,
+//                points of a voxel in stable order) and writes them at the offset it learns from
+//                its predecessors' published counts (decoupled look-back)       [16 B r, 16 B/voxel w]
+// G = 1..3 global passes depending on the key width; the local finish handles what is left.
+//
+// The voxel keys need the grid before the first point is read, so this path runs only when the host
+// knows a box that contains the cloud: the crop box, or the previous frame's bounds plus a margin
+// (cm_api.cpp). Keys are linear indices in that box: the same order as PCL's (x fastest), so kept
+// voxels, their order and their point sums are those of pcl::VoxelGrid; a point
+// outside a predicted box raises CmFrameState.outside and the host redoes the frame with
+// cm_kernels.hip. A bucket that does not fit LDS raises CM_DEV_ERR_BUCKET, same remedy.
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "cm_common.hpp"
+#include "cm_device.h"
+#include "cm_kernels.h"
+
+namespace {
+
+template <int WAVES>
+__device__ __forceinline__ uint32_t block_excl_scan_w(uint32_t v, uint32_t* lds, uint32_t* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan_u32(v, lane);
+    if (lane == 63) lds[w] = incl;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < WAVES; ++k) {
+        const uint32_t c = lds[k];
+        if (k < w) woff += c;
+        tot += c;
+    }
+    __syncthreads();
+    *total = tot;
+    return woff + incl - v;
+}
+
+template <int WAVES>
+__device__ __forceinline__ uint32_t block_sum_w(uint32_t v, uint32_t* lds) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t tot = 0;
+#pragma unroll
+    for (int k = 0; k < WAVES; ++k) tot += lds[k];
+    __syncthreads();
+    return tot;
+}
+
+// The box grid k2_hist0 recorded in the frame state (compute_grid on the crop box / predicted box).
+struct BoxGrid {
+    float inv0, inv1, inv2, fb0, fb1, fb2;
+    int d0, d1, d2;
+    uint32_t mul1, mul2;
+};
+
+__device__ __forceinline__ BoxGrid box_grid_of(const CmFrameDev* __restrict__ fd, const int* min_b, const int* div_b) {
+    BoxGrid b;
+    b.inv0 = fd->inv_leaf[0]; b.inv1 = fd->inv_leaf[1]; b.inv2 = fd->inv_leaf[2];
+    b.fb0 = static_cast<float>(min_b[0]); b.fb1 = static_cast<float>(min_b[1]); b.fb2 = static_cast<float>(min_b[2]);
+    b.d0 = div_b[0]; b.d1 = div_b[1]; b.d2 = div_b[2];
+    b.mul1 = static_cast<uint32_t>(div_b[0]);
+    b.mul2 = b.mul1 * static_cast<uint32_t>(div_b[1]);
+    return b;
+}
+
+// Cell of a transformed point, PCL's arithmetic (A.4 step 5). `inside`: the cell lies in the box.
+__device__ __forceinline__ uint32_t key_of(const BoxGrid& b, float x, float y, float z, bool* inside) {
+    const int c0 = static_cast<int>(__fsub_rn(floorf(__fmul_rn(x, b.inv0)), b.fb0));
+    const int c1 = static_cast<int>(__fsub_rn(floorf(__fmul_rn(y, b.inv1)), b.fb1));
+    const int c2 = static_cast<int>(__fsub_rn(floorf(__fmul_rn(z, b.inv2)), b.fb2));
+    *inside = c0 >= 0 && c0 < b.d0 && c1 >= 0 && c1 < b.d1 && c2 >= 0 && c2 < b.d2;
+    return static_cast<uint32_t>(c0) + static_cast<uint32_t>(c1) * b.mul1 + static_cast<uint32_t>(c2) * b.mul2;
+}
+__device__ __forceinline__ uint32_t key_of(const BoxGrid& b, const float4& r) {
+    bool in;
+    return key_of(b, r.x, r.y, r.z, &in);
+}
+
+__device__ __forceinline__ uint32_t sensor_of_slot(const CmFrameDev* __restrict__ fd, uint32_t first) {
+    uint32_t s = 0;
+    for (uint32_t q = 1; q < fd->n_sensors; ++q) s += (first >= fd->s[q].base) ? 1u : 0u;
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k2_hist0: per 4096-slot tile of the padded index space, counts of the first (lowest of the HIGH)
+// digit among the valid points; grid set-up recorded by workgroup 0; min/max/count record per tile.
+// Also clears what the later kernels of this frame (and the first kernel of the next) accumulate into.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(CM2_BLOCK) void k2_hist0(const CmFrameDev* __restrict__ fd,
+                                                      CmFrameState* __restrict__ st,
+                                                      uint32_t* __restrict__ hist,
+                                                      uint32_t* __restrict__ grp_acc,
+                                                      uint32_t* __restrict__ grp_clear_a,
+                                                      uint32_t* __restrict__ grp_clear_b,
+                                                      uint32_t n_group_words, uint32_t n_clear_a_words,
+                                                      unsigned long long* __restrict__ tile_state,
+                                                      uint32_t n_tile_state,
+                                                      float* __restrict__ records,
+                                                      int grid_mode, uint32_t shift0, uint32_t n_global_passes) {
+    __shared__ uint32_t lh[CM_RADIX];
+    __shared__ float s_red[CM_WAVES][8];
+    __shared__ float s_mm[CM2_WAVES][6];
+    __shared__ uint32_t s_cnt[CM2_WAVES];
+    __shared__ uint32_t s_out;
+    const uint32_t tile = blockIdx.x;
+    for (uint32_t k = tile * CM2_BLOCK + threadIdx.x; k < 3 * n_group_words; k += gridDim.x * CM2_BLOCK) grp_clear_b[k] = 0;
+    for (uint32_t k = tile * CM2_BLOCK + threadIdx.x; k < n_clear_a_words; k += gridDim.x * CM2_BLOCK) grp_clear_a[k] = 0;
+    for (uint32_t k = tile * CM2_BLOCK + threadIdx.x; k < n_tile_state; k += gridDim.x * CM2_BLOCK) tile_state[k] = 0ull;
+
+    Grid g;
+    compute_grid(fd, nullptr, 0, grid_mode, fd->inv_leaf, s_red, g);
+    if (tile == 0 && threadIdx.x == 0) {
+        st->status = g.status;
+        for (int a = 0; a < 3; ++a) {
+            st->min_p[a] = g.min_p[a]; st->max_p[a] = g.max_p[a];
+            st->min_b[a] = g.min_b[a]; st->max_b[a] = g.max_b[a]; st->div_b[a] = g.div_b[a];
+        }
+        st->key_bits = g.key_bits;
+        st->n_passes = n_global_passes;
+    }
+    if (g.status != CM_DEV_OK) return;
+    const BoxGrid b = box_grid_of(fd, g.min_b, g.div_b);
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t slot0 = tile * CM_TILE + w * (64 * CM2_ITEMS) + lane;
+    const CmSensorDev& sd = fd->s[sensor_of_slot(fd, tile * CM_TILE)];
+    float m[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) m[k] = sd.m[k];
+    const uint32_t crop = fd->crop_enable;
+    Pt p[CM2_ITEMS];
+    load_tile<CM2_ITEMS>(sd, slot0 - sd.base, p);
+    if (threadIdx.x < CM_RADIX) lh[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_out = 0;
+    __syncthreads();
+    const float inf = __uint_as_float(0x7F800000u);
+    float mn0 = inf, mn1 = inf, mn2 = inf, mx0 = -inf, mx1 = -inf, mx2 = -inf;
+    uint32_t cnt = 0;
+    bool any_out = false;
+#pragma unroll
+    for (int r = 0; r < CM2_ITEMS; ++r) {
+        const float x = xf_row(m[0], m[1], m[2], m[3], p[r].x, p[r].y, p[r].z);
+        const float y = xf_row(m[4], m[5], m[6], m[7], p[r].x, p[r].y, p[r].z);
+        const float z = xf_row(m[8], m[9], m[10], m[11], p[r].x, p[r].y, p[r].z);
+        if (point_valid(x, y, z, crop, fd->crop_min, fd->crop_max)) {
+            bool in;
+            const uint32_t key = key_of(b, x, y, z, &in);
+            any_out = any_out || !in;
+            if (in) atomicAdd(&lh[(key >> shift0) & (CM_RADIX - 1)], 1u);
+            mn0 = fminf(mn0, x); mx0 = fmaxf(mx0, x);
+            mn1 = fminf(mn1, y); mx1 = fmaxf(mx1, y);
+            mn2 = fminf(mn2, z); mx2 = fmaxf(mx2, z);
+            ++cnt;
+        }
+    }
+    if (any_out) s_out = 1u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        mn0 = fminf(mn0, __shfl_xor(mn0, d)); mx0 = fmaxf(mx0, __shfl_xor(mx0, d));
+        mn1 = fminf(mn1, __shfl_xor(mn1, d)); mx1 = fmaxf(mx1, __shfl_xor(mx1, d));
+        mn2 = fminf(mn2, __shfl_xor(mn2, d)); mx2 = fmaxf(mx2, __shfl_xor(mx2, d));
+        cnt += __shfl_xor(cnt, d);
+    }
+    if (lane == 0) {
+        s_mm[w][0] = mn0; s_mm[w][1] = mn1; s_mm[w][2] = mn2;
+        s_mm[w][3] = mx0; s_mm[w][4] = mx1; s_mm[w][5] = mx2;
+        s_cnt[w] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x < CM_RADIX) {
+        const uint32_t c = lh[threadIdx.x];
+        hist[static_cast<size_t>(tile) * CM_RADIX + threadIdx.x] = c;
+        if (c) atomicAdd(&grp_acc[static_cast<size_t>(tile / CM_GROUP) * CM_RADIX + threadIdx.x], c);
+    } else if (threadIdx.x < CM_RADIX + 8) {         // record: min xyz, max xyz, count, pad
+        const int k = threadIdx.x - CM_RADIX;
+        float v = 0.f;
+        if (k < 6) {
+            v = s_mm[0][k];
+            for (int q = 1; q < CM2_WAVES; ++q) v = (k < 3) ? fminf(v, s_mm[q][k]) : fmaxf(v, s_mm[q][k]);
+        } else if (k == 6) {
+            uint32_t c = 0;
+            for (int q = 0; q < CM2_WAVES; ++q) c += s_cnt[q];
+            v = __uint_as_float(c);
+        }
+        records[static_cast<size_t>(tile) * 8 + k] = v;
+    }
+    if (threadIdx.x == 0 && s_out) st->outside = 1u;
+}
+
+// Counts of the next digit per tile of the records, from the digit bytes the last scatter left.
+__global__ __launch_bounds__(CM2_BLOCK) void k2_hist(const CmFrameState* __restrict__ st,
+                                                     const unsigned char* __restrict__ dig,
+                                                     uint32_t* __restrict__ hist,
+                                                     uint32_t* __restrict__ grp) {
+    __shared__ uint32_t lh[CM_RADIX];
+    if (st->status != CM_DEV_OK || st->outside) return;
+    const uint32_t n = st->n_valid;
+    const uint32_t base = blockIdx.x * CM_TILE;
+    if (base >= n) return;
+    if (threadIdx.x < CM_RADIX) lh[threadIdx.x] = 0;
+    const uint32_t i0 = base + threadIdx.x * 8;
+    uint2 v = make_uint2(0u, 0u);
+    if (i0 < n) v = *reinterpret_cast<const uint2*>(dig + i0);     // the buffer is padded to whole tiles
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const uint32_t d = ((q < 4 ? v.x : v.y) >> ((q & 3) * 8)) & 0xFFu;
+        if (i0 + q < n) atomicAdd(&lh[d], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < CM_RADIX) {
+        const uint32_t c = lh[threadIdx.x];
+        hist[static_cast<size_t>(blockIdx.x) * CM_RADIX + threadIdx.x] = c;
+        if (c) atomicAdd(&grp[static_cast<size_t>(blockIdx.x / CM_GROUP) * CM_RADIX + threadIdx.x], c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k2_scatter: stable scatter of one 4096-record tile by one 8-bit digit; the record itself moves.
+// FIRST: reads the raw sensor points (transform + crop once more, dropping invalid slots: this is
+// where the clouds get concatenated) and folds the min/max records (workgroup of tile 0).
+// Ranking: returning LDS adds per wave (cm_kernels.hip k_scatter<*, true>; the path is only
+// selected after the device probe passed).
+// ------------------------------------------------------------------------------------------------
+template <bool FIRST>
+__global__ __launch_bounds__(CM2_BLOCK, 2) void k2_scatter(const CmFrameDev* __restrict__ fd,
+                                                           CmFrameState* __restrict__ st,
+                                                           const float4* __restrict__ rec_in,
+                                                           float4* __restrict__ rec_out,
+                                                           unsigned char* __restrict__ dig_out,
+                                                           const uint32_t* __restrict__ hist,
+                                                           const uint32_t* __restrict__ grp,
+                                                           const uint32_t* __restrict__ totals,
+                                                           uint32_t shift, uint32_t next_shift,
+                                                           uint32_t n_groups, uint32_t n_padded,
+                                                           const float* __restrict__ records,
+                                                           uint32_t n_records, int fold) {
+    __shared__ float4 srec[CM_TILE];
+    __shared__ uint32_t whist[CM2_WAVES][CM_RADIX];
+    __shared__ uint32_t gofs[CM_RADIX];
+    __shared__ uint32_t lds[CM2_WAVES];
+    __shared__ uint32_t s_tile_valid;
+    if (st->status != CM_DEV_OK || st->outside) return;
+    uint32_t tile = blockIdx.x;
+    {
+        const uint32_t per = gridDim.x / 8;              // contiguous tile range per XCD (see k_scatter)
+        if (blockIdx.x < per * 8) tile = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    }
+    const BoxGrid b = box_grid_of(fd, st->min_b, st->div_b);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t first = tile * CM_TILE + w * (64 * CM2_ITEMS) + lane;
+
+    float4 rec[CM2_ITEMS];
+    uint32_t key[CM2_ITEMS];
+    uint32_t vmask = 0;
+    if (FIRST) {
+        const CmSensorDev& sd = fd->s[sensor_of_slot(fd, tile * CM_TILE)];
+        float m[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) m[k] = sd.m[k];
+        const uint32_t crop = fd->crop_enable;
+        const bool all_fields = fd->downsample_all != 0;
+        Pt p[CM2_ITEMS];
+        load_tile<CM2_ITEMS>(sd, first - sd.base, p);
+#pragma unroll
+        for (int r = 0; r < CM2_ITEMS; ++r) {
+            rec[r].x = xf_row(m[0], m[1], m[2], m[3], p[r].x, p[r].y, p[r].z);
+            rec[r].y = xf_row(m[4], m[5], m[6], m[7], p[r].x, p[r].y, p[r].z);
+            rec[r].z = xf_row(m[8], m[9], m[10], m[11], p[r].x, p[r].y, p[r].z);
+            rec[r].w = all_fields ? p[r].i : 0.f;
+            bool in = false;
+            key[r] = 0;
+            if (point_valid(rec[r].x, rec[r].y, rec[r].z, crop, fd->crop_min, fd->crop_max))
+                key[r] = key_of(b, rec[r].x, rec[r].y, rec[r].z, &in);
+            if (in) vmask |= 1u << r;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < CM2_ITEMS; ++r) {
+            const uint32_t i = first + r * 64;
+            rec[r] = (i < n_padded) ? rec_in[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+
+    // Records of digit d written before this tile's (thread d < 256), as in k_scatter.
+    const uint32_t grp_id = tile / CM_GROUP;
+    uint32_t before = 0, my_total = 0;
+    if (threadIdx.x < CM_RADIX) {
+        if (totals) {
+            my_total = totals[threadIdx.x];
+            before = grp[static_cast<size_t>(grp_id) * CM_RADIX + threadIdx.x];
+        } else {
+            for (uint32_t g = 0; g < n_groups; g += 16) {
+                uint32_t v[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) v[q] = (g + q < n_groups) ? grp[static_cast<size_t>(g + q) * CM_RADIX + threadIdx.x] : 0u;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { my_total += v[q]; before += (g + q < grp_id) ? v[q] : 0u; }
+            }
+        }
+        const uint32_t t0 = grp_id * CM_GROUP;
+        for (uint32_t t = t0; t < tile; t += 16) {
+            uint32_t v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = (t + q < tile) ? hist[static_cast<size_t>(t + q) * CM_RADIX + threadIdx.x] : 0u;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) before += v[q];
+        }
+    }
+    uint32_t gtot;
+    const uint32_t gbase = block_excl_scan_w<CM2_WAVES>(my_total, lds, &gtot);
+    if (FIRST && tile == 0 && threadIdx.x == 0) st->n_valid = gtot;
+    const uint32_t n = FIRST ? n_padded : gtot;
+    if (tile * CM_TILE >= n) return;                     // uniform (n is the same in every workgroup)
+
+    if (!FIRST) {
+#pragma unroll
+        for (int r = 0; r < CM2_ITEMS; ++r) {
+            key[r] = key_of(b, rec[r]);
+            if (first + r * 64 < n) vmask |= 1u << r;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < CM2_WAVES; ++q)
+        if (threadIdx.x < CM_RADIX) whist[q][threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t rank[CM2_ITEMS];
+#pragma unroll
+    for (int r = 0; r < CM2_ITEMS; ++r) {
+        const uint32_t digit = (key[r] >> shift) & (CM_RADIX - 1);
+        rank[r] = (vmask >> r & 1u) ? atomicAdd(&whist[w][digit], 1u) : 0u;
+    }
+    __syncthreads();
+    {
+        uint32_t tot = 0, c[CM2_WAVES];
+        const uint32_t d = threadIdx.x & (CM_RADIX - 1);
+        if (threadIdx.x < CM_RADIX) {
+#pragma unroll
+            for (int q = 0; q < CM2_WAVES; ++q) { c[q] = whist[q][d]; tot += c[q]; }
+        }
+        uint32_t tile_valid;
+        const uint32_t dbase = block_excl_scan_w<CM2_WAVES>(tot, lds, &tile_valid);
+        if (threadIdx.x < CM_RADIX) {
+            uint32_t run = dbase;
+#pragma unroll
+            for (int q = 0; q < CM2_WAVES; ++q) { whist[q][d] = run; run += c[q]; }
+            gofs[d] = gbase + before - dbase;
+            if (d == 0) s_tile_valid = tile_valid;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < CM2_ITEMS; ++r) {
+        if (vmask >> r & 1u) {
+            const uint32_t digit = (key[r] >> shift) & (CM_RADIX - 1);
+            srec[whist[w][digit] + rank[r]] = rec[r];
+        }
+    }
+    __syncthreads();
+    const uint32_t tile_valid = s_tile_valid;
+#pragma unroll
+    for (int j = 0; j < CM2_ITEMS; ++j) {
+        const uint32_t t = j * CM2_BLOCK + threadIdx.x;
+        if (t < tile_valid) {
+            const float4 r4 = srec[t];
+            const uint32_t k = key_of(b, r4);
+            const uint32_t pos = gofs[(k >> shift) & (CM_RADIX - 1)] + t;
+            rec_out[pos] = r4;
+            if (next_shift < 32u) dig_out[pos] = static_cast<unsigned char>((k >> next_shift) & 0xFFu);
+        }
+    }
+
+    // The exact bounds of the cloud (pcl::getMinMax3D) for the result and for the next frame's box.
+    if (FIRST && fold && tile == 0) {
+        __syncthreads();
+        float* s_f = reinterpret_cast<float*>(whist);         // [CM2_WAVES][8]
+        const float inf = __uint_as_float(0x7F800000u);
+        float v[6] = {inf, inf, inf, -inf, -inf, -inf};
+        uint32_t cnt = 0;
+        for (uint32_t r = threadIdx.x; r < n_records; r += CM2_BLOCK) {
+            const float4 lo = *reinterpret_cast<const float4*>(records + static_cast<size_t>(r) * 8);
+            const float4 hi = *reinterpret_cast<const float4*>(records + static_cast<size_t>(r) * 8 + 4);
+            v[0] = fminf(v[0], lo.x); v[1] = fminf(v[1], lo.y); v[2] = fminf(v[2], lo.z);
+            v[3] = fmaxf(v[3], lo.w); v[4] = fmaxf(v[4], hi.x); v[5] = fmaxf(v[5], hi.y);
+            cnt += __float_as_uint(hi.z);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[k] = fminf(v[k], __shfl_xor(v[k], d));
+#pragma unroll
+            for (int k = 3; k < 6; ++k) v[k] = fmaxf(v[k], __shfl_xor(v[k], d));
+            cnt += __shfl_xor(cnt, d);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s_f[w * 8 + k] = v[k];
+            s_f[w * 8 + 6] = __uint_as_float(cnt);
+        }
+        __syncthreads();
+        if (threadIdx.x < 7) {
+            const int k = threadIdx.x;
+            if (k < 6) {
+                float r = s_f[k];
+                for (int q = 1; q < CM2_WAVES; ++q) r = (k < 3) ? fminf(r, s_f[q * 8 + k]) : fmaxf(r, s_f[q * 8 + k]);
+                if (k < 3) st->min_p[k] = r; else st->max_p[k - 3] = r;
+            } else {
+                uint32_t c = 0;
+                for (int q = 0; q < CM2_WAVES; ++q) c += __float_as_uint(s_f[q * 8 + 6]);
+                st->n_valid_k0 = c;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k2_local: the finish. `rec` is grouped by H = key >> low_bits (ascending). Workgroup t owns the
+// buckets (runs of equal H) that START inside records [t*4096, (t+1)*4096): it skips the head of
+// its tile that continues the previous workgroup's last bucket and reads past its end until its
+// own last bucket closes. A voxel's points share H, so no voxel is ever split between workgroups.
+// ------------------------------------------------------------------------------------------------
+#define CM2_FLAG_AGG (1ull << 32)
+#define CM2_FLAG_PREFIX (2ull << 32)
+
+__global__ __launch_bounds__(CM2_LBLOCK) void k2_local(const CmFrameDev* __restrict__ fd,
+                                                       CmFrameState* __restrict__ st,
+                                                       CmFrameState* __restrict__ st_next,
+                                                       uint32_t* __restrict__ host_state,
+                                                       const float4* __restrict__ rec,
+                                                       unsigned long long* __restrict__ tile_state,
+                                                       float4* __restrict__ out,
+                                                       uint32_t* __restrict__ out_key,
+                                                       uint32_t* __restrict__ out_cnt,
+                                                       uint32_t low_bits) {
+    __shared__ float4 sp[CM2_LCAP];                    // records of the tile (never move)
+    __shared__ uint32_t sk[CM2_LCAP];                  // keys: by record slot, then sorted
+    __shared__ uint16_t si[CM2_LCAP];                  // record slot of every sorted key
+    __shared__ uint32_t whist[CM2_LWAVES][CM_RADIX];
+    __shared__ uint32_t dbase[CM_RADIX];
+    __shared__ uint32_t lds[CM2_LWAVES];
+    __shared__ float s_acc[CM2_LWAVES + 1][4];
+    __shared__ uint32_t s_accc[CM2_LWAVES + 1];
+    __shared__ uint32_t s_flag[CM2_LWAVES];
+    __shared__ uint32_t s_a, s_keyprev, s_off;
+
+    const uint32_t tile = blockIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (tile == 0 && st_next && threadIdx.x < sizeof(CmFrameState) / 4)
+        reinterpret_cast<uint32_t*>(st_next)[threadIdx.x] = 0;
+    if (st->status != CM_DEV_OK || st->outside) {
+        if (tile == 0) report_state(host_state, st, st->status, 0u, true);
+        return;
+    }
+    const uint32_t n = st->n_valid;
+    if (n == 0) {
+        if (tile == 0) report_state(host_state, st, CM_DEV_EMPTY, 0u, true);
+        return;
+    }
+    const uint32_t n_lt = (n + CM2_LT - 1) / CM2_LT;
+    if (tile >= n_lt) return;
+    const BoxGrid b = box_grid_of(fd, st->min_b, st->div_b);
+    const uint32_t L = low_bits;
+    const uint32_t min_pts = fd->min_pts > 1 ? fd->min_pts : 1u;
+
+    // ---- load: the nominal tile, the key before it, and the first 256 records after it
+    const uint32_t base = tile * CM2_LT;
+    const uint32_t nom = min(static_cast<uint32_t>(CM2_LT), n - base);
+    {
+        float4 r4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t q = r * CM2_LBLOCK + threadIdx.x;
+            r4[r] = (q < nom) ? rec[base + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const uint32_t j0 = base + CM2_LT + threadIdx.x;
+        const bool has_e = threadIdx.x < 256 && nom == CM2_LT && j0 < n;
+        const float4 e4 = has_e ? rec[j0] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (threadIdx.x == 0 && base > 0) pv = rec[base - 1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t q = r * CM2_LBLOCK + threadIdx.x;
+            if (q < nom) { sp[q] = r4[r]; sk[q] = key_of(b, r4[r]); }
+        }
+        if (has_e) { sp[CM2_LT + threadIdx.x] = e4; sk[CM2_LT + threadIdx.x] = key_of(b, e4); }
+        if (threadIdx.x == 0) { s_keyprev = base > 0 ? key_of(b, pv) : 0u; s_a = 0xFFFFFFFFu; }
+    }
+    __syncthreads();
+
+    // ---- a: first bucket start in the nominal tile
+    {
+        uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 3; r >= 0; --r) {
+            const uint32_t q = r * CM2_LBLOCK + threadIdx.x;
+            if (q < nom) {
+                const uint32_t kp = (q == 0) ? s_keyprev : sk[q - 1];
+                if ((base + q == 0) || ((sk[q] >> L) != (kp >> L))) best = q;
+            }
+        }
+        if (best != 0xFFFFFFFFu) atomicMin(&s_a, best);
+    }
+    const uint32_t h_last = sk[nom - 1] >> L;
+    // ---- tail of the last bucket past the nominal end (a prefix of what follows: H is ascending)
+    const bool m0 = threadIdx.x < 256 && nom == CM2_LT && (base + CM2_LT + threadIdx.x) < n &&
+                    (sk[CM2_LT + threadIdx.x] >> L) == h_last;
+    uint32_t ext = __syncthreads_count(m0);               // also orders the atomicMin above
+    const uint32_t a = s_a;
+    bool too_big = false;
+    if (ext == 256 && a != 0xFFFFFFFFu) {
+        for (uint32_t off = 256;; off += CM2_LBLOCK) {
+            const uint32_t j = base + CM2_LT + off + threadIdx.x;
+            const uint32_t pos = CM2_LT + off + threadIdx.x;
+            bool mm = false;
+            if (j < n) {
+                const float4 r4 = rec[j];
+                const uint32_t k = key_of(b, r4);
+                mm = (k >> L) == h_last;
+                if (mm && pos < CM2_LCAP) { sp[pos] = r4; sk[pos] = k; }
+            }
+            const uint32_t c = __syncthreads_count(mm);
+            ext += c;
+            if (CM2_LT + ext > CM2_LCAP) { too_big = true; break; }
+            if (c < CM2_LBLOCK) break;
+        }
+    }
+    uint32_t m = (a == 0xFFFFFFFFu || too_big) ? 0u : nom + ext - a;
+    if (too_big && threadIdx.x == 0) host_state[offsetof(CmFrameState, err) / 4] = CM_DEV_ERR_BUCKET;
+
+    // ---- sort the owned records by (key - first key of the first bucket): LSD, stable, in LDS
+    uint32_t kbase = 0;
+    if (m) {
+        const uint32_t h_base = sk[a] >> L;
+        kbase = h_base << L;
+        const unsigned long long span = static_cast<unsigned long long>(h_last - h_base + 1u) << L;
+        const uint32_t nb = span > 1ull ? 64u - static_cast<uint32_t>(__builtin_clzll(span - 1ull)) : 0u;
+        const uint32_t npass = nb ? (nb + 7u) / 8u : 1u;
+        const uint32_t width = nb ? (nb + npass - 1u) / npass : 0u;
+        const uint32_t dmask = (1u << width) - 1u;
+        __syncthreads();                                   // sk[a], sk[nom-1] read by everyone before pass 0 moves them
+        for (uint32_t p = 0; p < npass; ++p) {
+            uint32_t ek[CM2_LITEMS], rk[CM2_LITEMS];
+            uint16_t ei[CM2_LITEMS];
+#pragma unroll
+            for (int r = 0; r < CM2_LITEMS; ++r) {
+                const uint32_t e = w * (64 * CM2_LITEMS) + r * 64 + lane;
+                ek[r] = 0; ei[r] = 0;
+                if (e < m) {
+                    if (p == 0) { ek[r] = sk[a + e] - kbase; ei[r] = static_cast<uint16_t>(a + e); }
+                    else { ek[r] = sk[e]; ei[r] = si[e]; }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) (&whist[0][0])[q * CM2_LBLOCK + threadIdx.x] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < CM2_LITEMS; ++r) {
+                const uint32_t e = w * (64 * CM2_LITEMS) + r * 64 + lane;
+                rk[r] = (e < m) ? atomicAdd(&whist[w][(ek[r] >> (p * width)) & dmask], 1u) : 0u;
+            }
+            __syncthreads();
+            uint32_t tot = 0;
+            if (threadIdx.x < CM_RADIX) {
+#pragma unroll
+                for (int q = 0; q < CM2_LWAVES; ++q) {
+                    const uint32_t c = whist[q][threadIdx.x];
+                    whist[q][threadIdx.x] = tot;
+                    tot += c;
+                }
+            }
+            uint32_t all;
+            const uint32_t db = block_excl_scan_w<CM2_LWAVES>(tot, lds, &all);
+            if (threadIdx.x < CM_RADIX) dbase[threadIdx.x] = db;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < CM2_LITEMS; ++r) {
+                const uint32_t e = w * (64 * CM2_LITEMS) + r * 64 + lane;
+                if (e < m) {
+                    const uint32_t d = (ek[r] >> (p * width)) & dmask;
+                    const uint32_t pos = dbase[d] + whist[w][d] + rk[r];
+                    sk[pos] = ek[r];
+                    si[pos] = ei[r];
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- kept voxels of this tile (A.4 step 7: a run of at least min_pts), published at once
+    uint32_t my_keep = 0;
+#pragma unroll
+    for (int r = 0; r < CM2_LITEMS; ++r) {
+        const uint32_t e = r * CM2_LBLOCK + threadIdx.x;
+        if (e < m) {
+            const uint32_t k = sk[e];
+            if (e == 0 || sk[e - 1] != k) {
+                const uint32_t last = e + min_pts - 1u;
+                my_keep += (last >= e && last < m && sk[last] == k) ? 1u : 0u;
+            }
+        }
+    }
+    const uint32_t c_t = block_sum_w<CM2_LWAVES>(my_keep, lds);
+    if (threadIdx.x == 0) {
+        const unsigned long long v = (tile == 0 ? CM2_FLAG_PREFIX : CM2_FLAG_AGG) | c_t;
+        __hip_atomic_store(&tile_state[tile], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    // ---- runs -> sums: thread t owns sorted items [6t, 6t+6), as k_seg_reduce does with 8
+    const uint32_t i0 = threadIdx.x * CM2_LITEMS;
+    uint32_t k[CM2_LITEMS];
+    uint32_t heads = 0, live = 0, need = 0;
+    const uint32_t kprev = (i0 > 0 && i0 < m) ? sk[i0 - 1] : 0u;
+    const bool has_next = i0 + CM2_LITEMS < m;
+    const uint32_t knext = has_next ? sk[i0 + CM2_LITEMS] : 0u;
+#pragma unroll
+    for (int j = 0; j < CM2_LITEMS; ++j) k[j] = (i0 + j < m) ? sk[i0 + j] : 0u;
+#pragma unroll
+    for (int j = 0; j < CM2_LITEMS; ++j) {
+        const uint32_t i = i0 + j;
+        if (i < m) {
+            live |= 1u << j;
+            const uint32_t pk = (j == 0) ? kprev : k[(j + CM2_LITEMS - 1) % CM2_LITEMS];
+            const bool head = (i == 0) || (pk != k[j]);
+            const bool same_next = (j == CM2_LITEMS - 1) ? (has_next && knext == k[j])
+                                                         : (i + 1 < m && k[(j + 1) % CM2_LITEMS] == k[j]);
+            if (head) heads |= 1u << j;
+            if (min_pts <= 1 || !head || same_next) need |= 1u << j;
+        }
+    }
+    Acc it[CM2_LITEMS];
+#pragma unroll
+    for (int j = 0; j < CM2_LITEMS; ++j) {
+        it[j].x = it[j].y = it[j].z = it[j].i = 0.f; it[j].c = 1u;
+        if (need >> j & 1u) {
+            const float4 r4 = sp[si[i0 + j]];
+            it[j].x = r4.x; it[j].y = r4.y; it[j].z = r4.z; it[j].i = r4.w;
+        }
+    }
+    Acc pre = {0.f, 0.f, 0.f, 0.f, 0u};
+    Acc run = {0.f, 0.f, 0.f, 0.f, 0u};
+    Acc fin[CM2_LITEMS];
+    uint32_t fkey[CM2_LITEMS];
+    uint32_t fmask = 0, run_key = 0;
+    bool open = false;
+#pragma unroll
+    for (int j = 0; j < CM2_LITEMS; ++j) {
+        fin[j].x = fin[j].y = fin[j].z = fin[j].i = 0.f; fin[j].c = 0; fkey[j] = 0;
+        if (live >> j & 1u) {
+            if (heads >> j & 1u) {
+                if (open) { fin[j] = run; fkey[j] = run_key; fmask |= 1u << j; }
+                run = it[j]; run_key = k[j]; open = true;
+            } else if (open) {
+                acc_add(run, it[j]);
+            } else if (pre.c == 0) {
+                pre = it[j];
+            } else {
+                acc_add(pre, it[j]);
+            }
+        }
+    }
+    const bool has_head = open;
+    // wave64 segmented suffix scan of `pre`: S[t] = pre[t] + (has_head[t] ? 0 : S[t+1])
+    Acc S = pre;
+    uint32_t flag = has_head ? 1u : 0u;
+    if (__ballot(has_head) != ~0ull) {
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const Acc o = acc_shfl_down(S, d);
+            const uint32_t of = __shfl_down(flag, d);
+            if (lane + d < 64 && !flag) {
+                if (S.c == 0) S = o; else if (o.c) acc_add(S, o);
+                flag |= of;
+            }
+        }
+    }
+    if (lane == 0) {
+        s_acc[w][0] = S.x; s_acc[w][1] = S.y; s_acc[w][2] = S.z; s_acc[w][3] = S.i;
+        s_accc[w] = S.c; s_flag[w] = flag;
+    }
+    if (threadIdx.x == 0) {
+        s_acc[CM2_LWAVES][0] = s_acc[CM2_LWAVES][1] = s_acc[CM2_LWAVES][2] = s_acc[CM2_LWAVES][3] = 0.f;
+        s_accc[CM2_LWAVES] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                       // resolve the wave chain right to left
+        for (int q = CM2_LWAVES - 1; q >= 0; --q) {
+            if (!s_flag[q] && s_accc[q + 1]) {
+                if (s_accc[q] == 0) {
+                    for (int e = 0; e < 4; ++e) s_acc[q][e] = s_acc[q + 1][e];
+                } else {
+                    for (int e = 0; e < 4; ++e) s_acc[q][e] = __fadd_rn(s_acc[q][e], s_acc[q + 1][e]);
+                }
+                s_accc[q] += s_accc[q + 1];
+            }
+        }
+    }
+    __syncthreads();
+    if (!flag) {
+        const Acc o = {s_acc[w + 1][0], s_acc[w + 1][1], s_acc[w + 1][2], s_acc[w + 1][3], s_accc[w + 1]};
+        if (S.c == 0) S = o; else if (o.c) acc_add(S, o);
+    }
+    Acc carry = acc_shfl_down(S, 1);
+    if (lane == 63) {
+        carry.x = s_acc[w + 1][0]; carry.y = s_acc[w + 1][1]; carry.z = s_acc[w + 1][2];
+        carry.i = s_acc[w + 1][3]; carry.c = s_accc[w + 1];
+    }
+    if (has_head && carry.c) acc_add(run, carry);
+
+    uint32_t nkeep = (has_head && run.c >= min_pts) ? 1u : 0u;
+#pragma unroll
+    for (int j = 0; j < CM2_LITEMS; ++j)
+        if ((fmask >> j & 1u) && fin[j].c >= min_pts) ++nkeep;
+    uint32_t tot;
+    const uint32_t local_slot = block_excl_scan_w<CM2_LWAVES>(nkeep, lds, &tot);
+
+    // ---- output offset: kept voxels of every earlier tile (decoupled look-back, wave 0)
+    if (w == 0) {
+        uint32_t excl = 0;
+        bool timed_out = false;
+        for (int j = static_cast<int>(tile) - 1; j >= 0; j -= 64) {
+            const int jj = j - lane;
+            unsigned long long v = CM2_FLAG_PREFIX;             // lanes before tile 0: an empty prefix
+            if (jj >= 0) {
+                uint32_t spins = 0;
+                do {
+                    v = __hip_atomic_load(&tile_state[jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v >> 32) break;
+                    __builtin_amdgcn_s_sleep(2);
+                } while (++spins < (1u << 18));
+                if (!(v >> 32)) { timed_out = true; v = CM2_FLAG_PREFIX; }
+            }
+            const unsigned long long pm = __ballot((v & CM2_FLAG_PREFIX) != 0);
+            const int first_p = pm ? __builtin_ctzll(pm) : 64;         // nearest predecessor with a full prefix
+            uint32_t val = (lane <= first_p) ? static_cast<uint32_t>(v) : 0u;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) val += __shfl_xor(val, d);
+            excl += val;
+            if (pm) break;
+        }
+        if (lane == 0) {
+            if (tile > 0)
+                __hip_atomic_store(&tile_state[tile], CM2_FLAG_PREFIX | static_cast<unsigned long long>(excl + c_t),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_off = excl;
+        }
+        if (__ballot(timed_out) && lane == 0) host_state[offsetof(CmFrameState, err) / 4] = CM_DEV_ERR_LOOKBACK;
+    }
+    __syncthreads();
+    const uint32_t tile_off = s_off;
+    if (tile == n_lt - 1) report_state(host_state, st, CM_DEV_OK, tile_off + c_t, true);
+
+    uint32_t slot = tile_off + local_slot;
+#pragma unroll
+    for (int j = 0; j <= CM2_LITEMS; ++j) {
+        const bool is_last = (j == CM2_LITEMS);
+        const int jj = is_last ? 0 : j;
+        const bool emit = is_last ? (has_head && run.c >= min_pts) : ((fmask >> jj & 1u) && fin[jj].c >= min_pts);
+        if (emit) {
+            const Acc acc = is_last ? run : fin[jj];
+            const uint32_t ak = is_last ? run_key : fkey[jj];
+            const float c = static_cast<float>(acc.c);
+            float4 o;
+            o.x = __fdiv_rn(acc.x, c); o.y = __fdiv_rn(acc.y, c);
+            o.z = __fdiv_rn(acc.z, c); o.w = __fdiv_rn(acc.i, c);
+            out[slot] = o;
+            if (out_key) { out_key[slot] = ak + kbase; out_cnt[slot] = acc.c; }
+            ++slot;
+        }
+    }
+}
+
+}  // namespace
+
+void cmk2_hist0(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* hist, uint32_t* grp_acc,
+                uint32_t* grp_clear_a, uint32_t* grp_clear_b, uint32_t n_group_words, uint32_t n_clear_a_words,
+                unsigned long long* tile_state, uint32_t n_tile_state, float* records, int grid_mode,
+                uint32_t shift0, uint32_t n_global_passes, uint32_t n_tiles) {
+    hipLaunchKernelGGL(k2_hist0, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, st, hist, grp_acc, grp_clear_a, grp_clear_b,
+                       n_group_words, n_clear_a_words, tile_state, n_tile_state, records, grid_mode, shift0,
+                       n_global_passes);
+}
+void cmk2_hist(hipStream_t s, const CmFrameState* st, const unsigned char* dig, uint32_t* hist, uint32_t* grp,
+               uint32_t n_tiles) {
+    hipLaunchKernelGGL(k2_hist, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, st, dig, hist, grp);
+}
+void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, CmFrameState* st, const void* rec_in, void* rec_out,
+                  unsigned char* dig_out, const uint32_t* hist, const uint32_t* grp, const uint32_t* totals,
+                  uint32_t shift, uint32_t next_shift, uint32_t n_tiles, uint32_t n_groups, uint32_t n_padded,
+                  const float* records, uint32_t n_records, int fold) {
+    const float4* in = reinterpret_cast<const float4*>(rec_in);
+    float4* o = reinterpret_cast<float4*>(rec_out);
+    if (first)
+        hipLaunchKernelGGL(k2_scatter<true>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, st, in, o, dig_out, hist, grp,
+                           totals, shift, next_shift, n_groups, n_padded, records, n_records, fold);
+    else
+        hipLaunchKernelGGL(k2_scatter<false>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, st, in, o, dig_out, hist, grp,
+                           totals, shift, next_shift, n_groups, n_padded, records, n_records, fold);
+}
+void cmk2_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next, uint32_t* host_state,
+                const void* rec, unsigned long long* tile_state, void* out, uint32_t* out_key, uint32_t* out_cnt,
+                uint32_t low_bits, uint32_t n_local_tiles) {
+    hipLaunchKernelGGL(k2_local, dim3(n_local_tiles), dim3(CM2_LBLOCK), 0, s, fd, st, st_next, host_state,
+                       reinterpret_cast<const float4*>(rec), tile_state, reinterpret_cast<float4*>(out), out_key,
+                       out_cnt, low_bits);
+}

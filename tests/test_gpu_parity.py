@@ -15,6 +15,17 @@ from tests.util import (assert_centroids_close, bits_to_xyzi, case_inputs, load_
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["auto", "classic"])
+def sort_path(request, monkeypatch):
+    """Every test runs twice: CM_PATH=auto (the bucket path of cm_kernels_v2.hip wherever it applies,
+    result path_flags & 2) and CM_PATH=classic (cm_kernels.hip only). Read by cm_create."""
+    monkeypatch.setenv("CM_PATH", request.param)
+    return request.param
+
+
+BUCKET, PREDICTED = 2, 4          # cm_result.path_flags
+
 STATUS = {"OK": capi.OK, "EMPTY_INPUT": capi.EMPTY_INPUT, "GRID_OVERFLOW": capi.GRID_OVERFLOW}
 
 
@@ -102,21 +113,28 @@ def test_config1_plumbing():
 
 
 @pytest.mark.parametrize("min_pts", [0, 2])
-def test_config2_scaled(min_pts):
+def test_config2_scaled(min_pts, sort_path):
     sensors, params = synth.config2(n_per_sensor=150_000, min_pts=min_pts)
-    check_against_oracle(sensors, params, exact_small_runs=True)
+    g, rep = check_against_oracle(sensors, params, exact_small_runs=True)
+    want = (BUCKET | PREDICTED) if sort_path == "auto" else 0      # no crop box: box predicted from the bounds
+    assert g["res"].path_flags & (BUCKET | PREDICTED) == want
 
 
 def test_config2_full_size():
     sensors, params = synth.config2(min_pts=2)          # 4 x 1 M, 5 cm: the headline workload
     g, rep = check_against_oracle(sensors, params, exact_small_runs=True)
-    assert g["res"].n_in == 4_000_000 and g["res"].sort_passes == 4
+    assert g["res"].n_in == 4_000_000
+    assert g["res"].sort_passes == (2 if g["res"].path_flags & BUCKET else 4)
 
 
-def test_config3_crop_scaled():
+def test_config3_crop_scaled(sort_path):
     sensors, params = synth.config3(n_per_sensor=300_000, min_pts=0)
     g, rep = check_against_oracle(sensors, params)
     assert g["res"].bounds_from_crop == 1 and 0 < g["res"].n_merged < g["res"].n_in
+    if sort_path == "classic":
+        assert g["res"].path_flags & (BUCKET | PREDICTED) == 0
+    else:
+        assert g["res"].path_flags & PREDICTED == 0               # the crop box is the box
 
 
 def test_config3_full_size_properties():
@@ -339,7 +357,10 @@ def test_profile_stage_times():
         res = cm.merge_voxelize(params)
         stages = cm.stage_times()
     names = [n for n, _ in stages]
-    assert "k_keys" in names and ("k_radix_pass" in names or "k_scatter" in names) and "k_seg_reduce" in names
+    if res.path_flags & BUCKET:
+        assert "k2_hist0" in names and "k2_scatter" in names and "k2_local" in names
+    else:
+        assert "k_keys" in names and "k_scatter" in names and "k_seg_reduce" in names
     assert res.device_ms > 0 and all(ms >= 0 for _, ms in stages)
 
 
@@ -372,7 +393,7 @@ def test_both_ranking_variants(force):
     env = dict(os.environ, CM_LDS_RANK=force)
     r = subprocess.run([sys.executable, "-c", _BALLOT_SCRIPT, root], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.strip().endswith("flags " + force)
+    assert int(r.stdout.strip().split()[-1]) & 1 == int(force)
 
 
 # ---- radius outlier removal on the fused cloud -------------------------
