@@ -97,6 +97,7 @@ struct cm_ctx {
     float* records = nullptr;            // min/max/count per tile
     bool pred_ok = false;                // a box predicted from an earlier frame's bounds
     float pred_min[3] = {0, 0, 0}, pred_max[3] = {0, 0, 0};
+    int v2_variant = 1;                  // local finish geometry: 1 2048-record tiles (2 workgroups/CU), 2 4096 (1/CU, longer bucket tails)
     uint32_t v2_extra_passes = 0;        // buckets overflowed LDS: sort more bits globally
     uint32_t v2_off_frames = 0;          // ... or give the path a rest
     bool last_v2 = false, last_predicted = false;
@@ -372,7 +373,7 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
     if (!c->rec_a) HIP_TRY(c, hipMalloc(&c->rec_a, npad * 16));
     if (!c->rec_b) HIP_TRY(c, hipMalloc(&c->rec_b, npad * 16));
     if (!c->dig) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->dig), npad));
-    if (!c->tile_state) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->tile_state), (npad / CM2_LT + 1) * 8));
+    if (!c->tile_state) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->tile_state), (npad / 1024 + 1) * 8));
     if (!c->records) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->records), static_cast<size_t>(c->cap_tiles) * 32));
     if (!c->frame_uploaded_valid || std::memcmp(&f, &c->frame_uploaded, sizeof f) != 0) {
         prof_mark(c, "k_setup");
@@ -397,7 +398,7 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
     c->frame_mask = nullptr;
     prof_mark(c, "k2_hist0");
     cmk2_hist0(st, c->d_frame, state, c->hist, grp0, grp0_next, c->grp + 2 * gstride, gw, static_cast<uint32_t>(gstride),
-               c->tile_state, nt + 1, c->records, grid_mode, low_bits, n_global, nt);
+               c->tile_state, f.n_padded / 1024 + 1, c->records, grid_mode, low_bits, n_global, nt);
     for (uint32_t pass = 0; pass < n_global; ++pass) {
         uint32_t* grp = pass == 0 ? grp0 : c->grp + 2 * gstride + static_cast<size_t>(pass - 1) * gw;
         if (pass > 0) { prof_mark(c, "k2_hist"); cmk2_hist(st, state, c->dig, c->hist, grp, nt); }
@@ -411,7 +412,7 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
     }
     prof_mark(c, "k2_local");
     cmk2_local(st, c->d_frame, state, state_next, c->h_state_dev, ((n_global - 1) & 1u) ? c->rec_b : c->rec_a,
-               c->tile_state, c->out, c->out_key, c->out_cnt, low_bits, nt);
+               c->tile_state, c->out, c->out_key, c->out_cnt, low_bits, f.n_padded, c->v2_variant);
     prof_mark(c, "end");
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_done, st));
@@ -794,6 +795,7 @@ int cm_create(cm_ctx** out, int device, const cm_limits* lim) {
     ok = ok && hipMemset(c->d_state[1], 0, sizeof(CmFrameState)) == hipSuccess;
     ok = ok && hipDeviceSynchronize() == hipSuccess;
     if (const char* pm = getenv("CM_PATH")) c->path_mode = std::strcmp(pm, "classic") == 0 ? 1 : 0;
+    if (const char* lv = getenv("CM_LOCAL_VARIANT")) c->v2_variant = std::atoi(lv) >= 2 ? 2 : 1;
     if (ok) {
         // Probe the device once: lane-ordered returning LDS adds allow the cheap stable ranking.
         // CM_LDS_RANK=0 forces the ballot-match ranking, CM_LDS_RANK=1 skips the probe.

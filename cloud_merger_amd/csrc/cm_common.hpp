@@ -63,13 +63,35 @@ __device__ __forceinline__ bool point_valid(float x, float y, float z, uint32_t 
     return ok;
 }
 
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(v, d);
-        if (lane >= d) v += t;
-    }
+// Inclusive wave64 scan on the DPP datapath (no LDS traffic, 6 VALU adds): shifts by 1, 2, 4, 8 lanes
+// inside each row of 16, then lane 15 of rows 0 and 2 into rows 1 and 3, then lane 31 into rows 2-3.
+// A lane without a source reads the first operand (the identity).
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int /*lane*/) {
+    int x = static_cast<int>(v);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);      // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);      // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);      // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);      // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
+    return static_cast<uint32_t>(x);
+}
+// Sum over the wave, in every lane.
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wave_incl_scan_u32(v, 0)), 63));
+}
+// min / max over the wave, valid in lane 63 (same DPP ladder; a lane without a source keeps its own value).
+__device__ __forceinline__ float wave_min_f32_l63(float v) {
+#define CM_DPP_F(ctrl, rmask) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rmask, 0xf, false))
+    v = fminf(v, CM_DPP_F(0x111, 0xf)); v = fminf(v, CM_DPP_F(0x112, 0xf)); v = fminf(v, CM_DPP_F(0x114, 0xf));
+    v = fminf(v, CM_DPP_F(0x118, 0xf)); v = fminf(v, CM_DPP_F(0x142, 0xa)); v = fminf(v, CM_DPP_F(0x143, 0xc));
     return v;
+}
+__device__ __forceinline__ float wave_max_f32_l63(float v) {
+    v = fmaxf(v, CM_DPP_F(0x111, 0xf)); v = fmaxf(v, CM_DPP_F(0x112, 0xf)); v = fmaxf(v, CM_DPP_F(0x114, 0xf));
+    v = fmaxf(v, CM_DPP_F(0x118, 0xf)); v = fmaxf(v, CM_DPP_F(0x142, 0xa)); v = fmaxf(v, CM_DPP_F(0x143, 0xc));
+    return v;
+#undef CM_DPP_F
 }
 
 // Exclusive scan over the 256 threads of a workgroup. lds: CM_WAVES words. Ends with a barrier.
@@ -91,8 +113,7 @@ __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* ld
 }
 
 __device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t* lds) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    v = wave_sum_u32(v);
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
     __syncthreads();
     uint32_t tot = 0;

@@ -55,4 +55,4 @@ void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, CmFrameState*
                   const float* records, uint32_t n_records, int fold);
 void cmk2_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next, uint32_t* host_state,
                 const void* rec, unsigned long long* tile_state, void* out, uint32_t* out_key, uint32_t* out_cnt,
-                uint32_t low_bits, uint32_t n_local_tiles);
+                uint32_t low_bits, uint32_t n_padded, int variant);

@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "cm_common.hpp"
 #include "cm_device.h"
@@ -53,8 +54,7 @@ __device__ __forceinline__ uint32_t block_excl_scan_w(uint32_t v, uint32_t* lds,
 
 template <int WAVES>
 __device__ __forceinline__ uint32_t block_sum_w(uint32_t v, uint32_t* lds) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    v = wave_sum_u32(v);
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
     __syncthreads();
     uint32_t tot = 0;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(CM2_BLOCK) void k2_hist0(const CmFrameDev* __restri
     if (threadIdx.x < CM_RADIX) {
         const uint32_t c = lh[threadIdx.x];
         hist[static_cast<size_t>(tile) * CM_RADIX + threadIdx.x] = c;
-        if (c) atomicAdd(&grp_acc[static_cast<size_t>(tile / CM_GROUP) * CM_RADIX + threadIdx.x], c);
+        if (c && !(shift0 & 0x100u)) atomicAdd(&grp_acc[static_cast<size_t>(tile / CM_GROUP) * CM_RADIX + threadIdx.x], c);
     } else if (threadIdx.x < CM_RADIX + 8) {         // record: min xyz, max xyz, count, pad
         const int k = threadIdx.x - CM_RADIX;
         float v = 0.f;
@@ -441,7 +441,8 @@ __global__ __launch_bounds__(CM2_BLOCK, 2) void k2_scatter(const CmFrameDev* __r
 #define CM2_FLAG_AGG (1ull << 32)
 #define CM2_FLAG_PREFIX (2ull << 32)
 
-__global__ __launch_bounds__(CM2_LBLOCK) void k2_local(const CmFrameDev* __restrict__ fd,
+template <int LT, int LCAP, int LBLOCK>
+__global__ __launch_bounds__(LBLOCK) void k2_local(const CmFrameDev* __restrict__ fd,
                                                        CmFrameState* __restrict__ st,
                                                        CmFrameState* __restrict__ st_next,
                                                        uint32_t* __restrict__ host_state,
@@ -450,17 +451,17 @@ __global__ __launch_bounds__(CM2_LBLOCK) void k2_local(const CmFrameDev* __restr
                                                        float4* __restrict__ out,
                                                        uint32_t* __restrict__ out_key,
                                                        uint32_t* __restrict__ out_cnt,
-                                                       uint32_t low_bits) {
-    __shared__ float4 sp[CM2_LCAP];                    // records of the tile (never move)
-    __shared__ uint32_t sk[CM2_LCAP];                  // keys: by record slot, then sorted
-    __shared__ uint16_t si[CM2_LCAP];                  // record slot of every sorted key
-    __shared__ uint32_t whist[CM2_LWAVES][CM_RADIX];
-    __shared__ uint32_t dbase[CM_RADIX];
-    __shared__ uint32_t lds[CM2_LWAVES];
-    __shared__ float s_acc[CM2_LWAVES + 1][4];
-    __shared__ uint32_t s_accc[CM2_LWAVES + 1];
-    __shared__ uint32_t s_flag[CM2_LWAVES];
+                                                       uint32_t low_bits, uint32_t dbg) {
+    constexpr int LWAVES = LBLOCK / 64, LITEMS = (LCAP + LBLOCK - 1) / LBLOCK, EXT0 = LBLOCK < 256 ? LBLOCK : 256;
+    constexpr int BINS = 1024, HWORDS = BINS / 2;          // two 16-bit counters per LDS word
+    static_assert(LT == 4 * LBLOCK && LCAP <= 0xFFFF && HWORDS <= LBLOCK && LWAVES * HWORDS * 2 >= LCAP, "tile geometry");
+    __shared__ float4 sp[LCAP];                        // records of the tile, by slot (never move)
+    __shared__ uint32_t sk[LCAP];                      // key of every slot
+    __shared__ uint16_t si[LCAP];                      // slots in sorted order
+    __shared__ uint32_t whist[LWAVES][HWORDS];         // digit counts per wave; after the sort: head positions
+    __shared__ uint32_t lds[LWAVES];
     __shared__ uint32_t s_a, s_keyprev, s_off;
+    uint16_t* hpos = reinterpret_cast<uint16_t*>(&whist[0][0]);
 
     const uint32_t tile = blockIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -475,33 +476,33 @@ __global__ __launch_bounds__(CM2_LBLOCK) void k2_local(const CmFrameDev* __restr
         if (tile == 0) report_state(host_state, st, CM_DEV_EMPTY, 0u, true);
         return;
     }
-    const uint32_t n_lt = (n + CM2_LT - 1) / CM2_LT;
+    const uint32_t n_lt = (n + LT - 1) / LT;
     if (tile >= n_lt) return;
     const BoxGrid b = box_grid_of(fd, st->min_b, st->div_b);
     const uint32_t L = low_bits;
     const uint32_t min_pts = fd->min_pts > 1 ? fd->min_pts : 1u;
 
-    // ---- load: the nominal tile, the key before it, and the first 256 records after it
-    const uint32_t base = tile * CM2_LT;
-    const uint32_t nom = min(static_cast<uint32_t>(CM2_LT), n - base);
+    // ---- load: the nominal tile, the key before it, and the first records after it
+    const uint32_t base = tile * LT;
+    const uint32_t nom = min(static_cast<uint32_t>(LT), n - base);
     {
         float4 r4[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const uint32_t q = r * CM2_LBLOCK + threadIdx.x;
+            const uint32_t q = r * LBLOCK + threadIdx.x;
             r4[r] = (q < nom) ? rec[base + q] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        const uint32_t j0 = base + CM2_LT + threadIdx.x;
-        const bool has_e = threadIdx.x < 256 && nom == CM2_LT && j0 < n;
+        const uint32_t j0 = base + LT + threadIdx.x;
+        const bool has_e = threadIdx.x < EXT0 && nom == LT && j0 < n;
         const float4 e4 = has_e ? rec[j0] : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (threadIdx.x == 0 && base > 0) pv = rec[base - 1];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const uint32_t q = r * CM2_LBLOCK + threadIdx.x;
+            const uint32_t q = r * LBLOCK + threadIdx.x;
             if (q < nom) { sp[q] = r4[r]; sk[q] = key_of(b, r4[r]); }
         }
-        if (has_e) { sp[CM2_LT + threadIdx.x] = e4; sk[CM2_LT + threadIdx.x] = key_of(b, e4); }
+        if (has_e) { sp[LT + threadIdx.x] = e4; sk[LT + threadIdx.x] = key_of(b, e4); }
         if (threadIdx.x == 0) { s_keyprev = base > 0 ? key_of(b, pv) : 0u; s_a = 0xFFFFFFFFu; }
     }
     __syncthreads();
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(CM2_LBLOCK) void k2_local(const CmFrameDev* __restr
         uint32_t best = 0xFFFFFFFFu;
 #pragma unroll
         for (int r = 3; r >= 0; --r) {
-            const uint32_t q = r * CM2_LBLOCK + threadIdx.x;
+            const uint32_t q = r * LBLOCK + threadIdx.x;
             if (q < nom) {
                 const uint32_t kp = (q == 0) ? s_keyprev : sk[q - 1];
                 if ((base + q == 0) || ((sk[q] >> L) != (kp >> L))) best = q;
@@ -521,83 +522,87 @@ __global__ __launch_bounds__(CM2_LBLOCK) void k2_local(const CmFrameDev* __restr
     }
     const uint32_t h_last = sk[nom - 1] >> L;
     // ---- tail of the last bucket past the nominal end (a prefix of what follows: H is ascending)
-    const bool m0 = threadIdx.x < 256 && nom == CM2_LT && (base + CM2_LT + threadIdx.x) < n &&
-                    (sk[CM2_LT + threadIdx.x] >> L) == h_last;
+    const bool m0 = threadIdx.x < EXT0 && nom == LT && (base + LT + threadIdx.x) < n &&
+                    (sk[LT + threadIdx.x] >> L) == h_last;
     uint32_t ext = __syncthreads_count(m0);               // also orders the atomicMin above
     const uint32_t a = s_a;
     bool too_big = false;
-    if (ext == 256 && a != 0xFFFFFFFFu) {
-        for (uint32_t off = 256;; off += CM2_LBLOCK) {
-            const uint32_t j = base + CM2_LT + off + threadIdx.x;
-            const uint32_t pos = CM2_LT + off + threadIdx.x;
+    if (ext == EXT0 && a != 0xFFFFFFFFu) {
+        for (uint32_t off = EXT0;; off += LBLOCK) {
+            const uint32_t j = base + LT + off + threadIdx.x;
+            const uint32_t pos = LT + off + threadIdx.x;
             bool mm = false;
             if (j < n) {
                 const float4 r4 = rec[j];
                 const uint32_t k = key_of(b, r4);
                 mm = (k >> L) == h_last;
-                if (mm && pos < CM2_LCAP) { sp[pos] = r4; sk[pos] = k; }
+                if (mm && pos < LCAP) { sp[pos] = r4; sk[pos] = k; }
             }
             const uint32_t c = __syncthreads_count(mm);
             ext += c;
-            if (CM2_LT + ext > CM2_LCAP) { too_big = true; break; }
-            if (c < CM2_LBLOCK) break;
+            if (LT + ext > LCAP) { too_big = true; break; }
+            if (c < LBLOCK) break;
         }
     }
-    uint32_t m = (a == 0xFFFFFFFFu || too_big) ? 0u : nom + ext - a;
+    const uint32_t m = (a == 0xFFFFFFFFu || too_big) ? 0u : nom + ext - a;
     if (too_big && threadIdx.x == 0) host_state[offsetof(CmFrameState, err) / 4] = CM_DEV_ERR_BUCKET;
 
-    // ---- sort the owned records by (key - first key of the first bucket): LSD, stable, in LDS
-    uint32_t kbase = 0;
+    // ---- sort the owned slots [a, a+m) by key: LSD over the bits in which the keys of this tile can
+    // differ, up to 10 per pass, stable. Only the slot numbers move (si); a pass reads its digit
+    // through the slot. Ranking: returning LDS adds on per-wave counters (lane order, see k_scatter).
     if (m) {
-        const uint32_t h_base = sk[a] >> L;
-        kbase = h_base << L;
-        const unsigned long long span = static_cast<unsigned long long>(h_last - h_base + 1u) << L;
+        const uint32_t kbase = (sk[a] >> L) << L;
+        const unsigned long long span = static_cast<unsigned long long>(h_last - (sk[a] >> L) + 1u) << L;
         const uint32_t nb = span > 1ull ? 64u - static_cast<uint32_t>(__builtin_clzll(span - 1ull)) : 0u;
-        const uint32_t npass = nb ? (nb + 7u) / 8u : 1u;
+        uint32_t npass = nb ? (nb + 9u) / 10u : 1u;
         const uint32_t width = nb ? (nb + npass - 1u) / npass : 0u;
         const uint32_t dmask = (1u << width) - 1u;
-        __syncthreads();                                   // sk[a], sk[nom-1] read by everyone before pass 0 moves them
+        if (dbg & 1u) npass = 1;
         for (uint32_t p = 0; p < npass; ++p) {
-            uint32_t ek[CM2_LITEMS], rk[CM2_LITEMS];
-            uint16_t ei[CM2_LITEMS];
+            uint32_t dg[LITEMS], rk[LITEMS];
+            uint16_t ei[LITEMS];
 #pragma unroll
-            for (int r = 0; r < CM2_LITEMS; ++r) {
-                const uint32_t e = w * (64 * CM2_LITEMS) + r * 64 + lane;
-                ek[r] = 0; ei[r] = 0;
+            for (int r = 0; r < LITEMS; ++r) {
+                const uint32_t e = w * (64 * LITEMS) + r * 64 + lane;
+                ei[r] = 0; dg[r] = 0;
                 if (e < m) {
-                    if (p == 0) { ek[r] = sk[a + e] - kbase; ei[r] = static_cast<uint16_t>(a + e); }
-                    else { ek[r] = sk[e]; ei[r] = si[e]; }
+                    ei[r] = (p == 0) ? static_cast<uint16_t>(a + e) : si[e];
+                    dg[r] = ((sk[ei[r]] - kbase) >> (p * width)) & dmask;
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) (&whist[0][0])[q * CM2_LBLOCK + threadIdx.x] = 0;
+            for (int q = 0; q < LWAVES * HWORDS / LBLOCK; ++q) (&whist[0][0])[q * LBLOCK + threadIdx.x] = 0;
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < CM2_LITEMS; ++r) {
-                const uint32_t e = w * (64 * CM2_LITEMS) + r * 64 + lane;
-                rk[r] = (e < m) ? atomicAdd(&whist[w][(ek[r] >> (p * width)) & dmask], 1u) : 0u;
+            for (int r = 0; r < LITEMS; ++r) {
+                const uint32_t e = w * (64 * LITEMS) + r * 64 + lane;
+                const uint32_t sh = (dg[r] & 1u) * 16u;
+                rk[r] = (e < m) ? ((atomicAdd(&whist[w][dg[r] >> 1], 1u << sh) >> sh) & 0xFFFFu) : 0u;
             }
             __syncthreads();
-            uint32_t tot = 0;
-            if (threadIdx.x < CM_RADIX) {
+            // thread t < HWORDS: digits 2t and 2t+1 — exclusive prefix over the waves, then over the digits
+            uint32_t t0 = 0, t1 = 0;
+            if (threadIdx.x < HWORDS) {
 #pragma unroll
-                for (int q = 0; q < CM2_LWAVES; ++q) {
+                for (int q = 0; q < LWAVES; ++q) {
                     const uint32_t c = whist[q][threadIdx.x];
-                    whist[q][threadIdx.x] = tot;
-                    tot += c;
+                    whist[q][threadIdx.x] = t0 | (t1 << 16);
+                    t0 += c & 0xFFFFu; t1 += c >> 16;
                 }
             }
             uint32_t all;
-            const uint32_t db = block_excl_scan_w<CM2_LWAVES>(tot, lds, &all);
-            if (threadIdx.x < CM_RADIX) dbase[threadIdx.x] = db;
+            const uint32_t db = block_excl_scan_w<LWAVES>(t0 + t1, lds, &all);
+            if (threadIdx.x < HWORDS) {
+                const uint32_t add = db | ((db + t0) << 16);
+#pragma unroll
+                for (int q = 0; q < LWAVES; ++q) whist[q][threadIdx.x] += add;
+            }
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < CM2_LITEMS; ++r) {
-                const uint32_t e = w * (64 * CM2_LITEMS) + r * 64 + lane;
+            for (int r = 0; r < LITEMS; ++r) {
+                const uint32_t e = w * (64 * LITEMS) + r * 64 + lane;
                 if (e < m) {
-                    const uint32_t d = (ek[r] >> (p * width)) & dmask;
-                    const uint32_t pos = dbase[d] + whist[w][d] + rk[r];
-                    sk[pos] = ek[r];
+                    const uint32_t pos = ((whist[w][dg[r] >> 1] >> ((dg[r] & 1u) * 16u)) & 0xFFFFu) + rk[r];
                     si[pos] = ei[r];
                 }
             }
@@ -605,135 +610,85 @@ __global__ __launch_bounds__(CM2_LBLOCK) void k2_local(const CmFrameDev* __restr
         }
     }
 
-    // ---- kept voxels of this tile (A.4 step 7: a run of at least min_pts), published at once
-    uint32_t my_keep = 0;
+    // ---- voxels of the tile: a head is a sorted item whose key differs from the one before it.
+    // hpos[v] = sorted position of voxel v's first point (the counters' LDS is free now).
+    uint32_t heads = 0, nh = 0;
+    {
+        const uint32_t i0 = threadIdx.x * LITEMS;
+        uint32_t kp = (i0 > 0 && i0 < m) ? sk[si[i0 - 1]] : 0u;
 #pragma unroll
-    for (int r = 0; r < CM2_LITEMS; ++r) {
-        const uint32_t e = r * CM2_LBLOCK + threadIdx.x;
-        if (e < m) {
-            const uint32_t k = sk[e];
-            if (e == 0 || sk[e - 1] != k) {
-                const uint32_t last = e + min_pts - 1u;
-                my_keep += (last >= e && last < m && sk[last] == k) ? 1u : 0u;
+        for (int j = 0; j < LITEMS; ++j) {
+            if (i0 + j < m) {
+                const uint32_t k = sk[si[i0 + j]];
+                if (i0 + j == 0 || k != kp) { heads |= 1u << j; ++nh; }
+                kp = k;
             }
         }
     }
-    const uint32_t c_t = block_sum_w<CM2_LWAVES>(my_keep, lds);
+    uint32_t n_vox;
+    {
+        uint32_t v = block_excl_scan_w<LWAVES>(nh, lds, &n_vox);     // its barriers also retire the last reads of whist
+        const uint32_t i0 = threadIdx.x * LITEMS;
+#pragma unroll
+        for (int j = 0; j < LITEMS; ++j)
+            if (heads >> j & 1u) hpos[v++] = static_cast<uint16_t>(i0 + j);
+    }
+    __syncthreads();
+
+    // ---- kept voxels (A.4 step 7: at least min_pts points), published at once for the look-back
+    uint32_t vstart[LITEMS], vlen[LITEMS];
+    uint32_t nkeep = 0;
+#pragma unroll
+    for (int j = 0; j < LITEMS; ++j) {
+        const uint32_t v = j * LBLOCK + threadIdx.x;               // consecutive voxels in a wave: similar run lengths
+        vstart[j] = 0; vlen[j] = 0;
+        if (v < n_vox) {
+            vstart[j] = hpos[v];
+            vlen[j] = ((v + 1 < n_vox) ? hpos[v + 1] : m) - vstart[j];
+            if (vlen[j] < min_pts) vlen[j] = 0;
+            nkeep += vlen[j] ? 1u : 0u;
+        }
+    }
+    // Output slots must follow voxel order: voxel v = j * LBLOCK + t, so scan per j-row.
+    uint32_t row_base[LITEMS];
+    uint32_t c_t = 0;
+#pragma unroll
+    for (int j = 0; j < LITEMS; ++j) {
+        uint32_t tot = 0;
+        if (static_cast<uint32_t>(j) * LBLOCK < n_vox) {           // uniform
+            const uint32_t ex = block_excl_scan_w<LWAVES>(vlen[j] ? 1u : 0u, lds, &tot);
+            row_base[j] = c_t + ex;
+        } else {
+            row_base[j] = 0;
+        }
+        c_t += tot;
+    }
     if (threadIdx.x == 0) {
         const unsigned long long v = (tile == 0 ? CM2_FLAG_PREFIX : CM2_FLAG_AGG) | c_t;
         __hip_atomic_store(&tile_state[tile], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (dbg & 2u) return;
 
-    // ---- runs -> sums: thread t owns sorted items [6t, 6t+6), as k_seg_reduce does with 8
-    const uint32_t i0 = threadIdx.x * CM2_LITEMS;
-    uint32_t k[CM2_LITEMS];
-    uint32_t heads = 0, live = 0, need = 0;
-    const uint32_t kprev = (i0 > 0 && i0 < m) ? sk[i0 - 1] : 0u;
-    const bool has_next = i0 + CM2_LITEMS < m;
-    const uint32_t knext = has_next ? sk[i0 + CM2_LITEMS] : 0u;
+    // ---- centroid sums: one lane per kept voxel adds its points in sorted (= stable) order, the
+    // order pcl::VoxelGrid itself adds them in (A.4 step 6).
+    Acc acc[LITEMS];
 #pragma unroll
-    for (int j = 0; j < CM2_LITEMS; ++j) k[j] = (i0 + j < m) ? sk[i0 + j] : 0u;
-#pragma unroll
-    for (int j = 0; j < CM2_LITEMS; ++j) {
-        const uint32_t i = i0 + j;
-        if (i < m) {
-            live |= 1u << j;
-            const uint32_t pk = (j == 0) ? kprev : k[(j + CM2_LITEMS - 1) % CM2_LITEMS];
-            const bool head = (i == 0) || (pk != k[j]);
-            const bool same_next = (j == CM2_LITEMS - 1) ? (has_next && knext == k[j])
-                                                         : (i + 1 < m && k[(j + 1) % CM2_LITEMS] == k[j]);
-            if (head) heads |= 1u << j;
-            if (min_pts <= 1 || !head || same_next) need |= 1u << j;
-        }
-    }
-    Acc it[CM2_LITEMS];
-#pragma unroll
-    for (int j = 0; j < CM2_LITEMS; ++j) {
-        it[j].x = it[j].y = it[j].z = it[j].i = 0.f; it[j].c = 1u;
-        if (need >> j & 1u) {
-            const float4 r4 = sp[si[i0 + j]];
-            it[j].x = r4.x; it[j].y = r4.y; it[j].z = r4.z; it[j].i = r4.w;
-        }
-    }
-    Acc pre = {0.f, 0.f, 0.f, 0.f, 0u};
-    Acc run = {0.f, 0.f, 0.f, 0.f, 0u};
-    Acc fin[CM2_LITEMS];
-    uint32_t fkey[CM2_LITEMS];
-    uint32_t fmask = 0, run_key = 0;
-    bool open = false;
-#pragma unroll
-    for (int j = 0; j < CM2_LITEMS; ++j) {
-        fin[j].x = fin[j].y = fin[j].z = fin[j].i = 0.f; fin[j].c = 0; fkey[j] = 0;
-        if (live >> j & 1u) {
-            if (heads >> j & 1u) {
-                if (open) { fin[j] = run; fkey[j] = run_key; fmask |= 1u << j; }
-                run = it[j]; run_key = k[j]; open = true;
-            } else if (open) {
-                acc_add(run, it[j]);
-            } else if (pre.c == 0) {
-                pre = it[j];
-            } else {
-                acc_add(pre, it[j]);
+    for (int j = 0; j < LITEMS; ++j) {
+        acc[j].x = acc[j].y = acc[j].z = acc[j].i = 0.f; acc[j].c = 0;
+        if (vlen[j]) {
+            float4 s4 = sp[si[vstart[j]]];
+            for (uint32_t e = 1; e < vlen[j]; ++e) {
+                const float4 r4 = sp[si[vstart[j] + e]];
+                s4.x = __fadd_rn(s4.x, r4.x); s4.y = __fadd_rn(s4.y, r4.y);
+                s4.z = __fadd_rn(s4.z, r4.z); s4.w = __fadd_rn(s4.w, r4.w);
             }
+            acc[j].x = s4.x; acc[j].y = s4.y; acc[j].z = s4.z; acc[j].i = s4.w; acc[j].c = vlen[j];
         }
     }
-    const bool has_head = open;
-    // wave64 segmented suffix scan of `pre`: S[t] = pre[t] + (has_head[t] ? 0 : S[t+1])
-    Acc S = pre;
-    uint32_t flag = has_head ? 1u : 0u;
-    if (__ballot(has_head) != ~0ull) {
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const Acc o = acc_shfl_down(S, d);
-            const uint32_t of = __shfl_down(flag, d);
-            if (lane + d < 64 && !flag) {
-                if (S.c == 0) S = o; else if (o.c) acc_add(S, o);
-                flag |= of;
-            }
-        }
-    }
-    if (lane == 0) {
-        s_acc[w][0] = S.x; s_acc[w][1] = S.y; s_acc[w][2] = S.z; s_acc[w][3] = S.i;
-        s_accc[w] = S.c; s_flag[w] = flag;
-    }
-    if (threadIdx.x == 0) {
-        s_acc[CM2_LWAVES][0] = s_acc[CM2_LWAVES][1] = s_acc[CM2_LWAVES][2] = s_acc[CM2_LWAVES][3] = 0.f;
-        s_accc[CM2_LWAVES] = 0;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {                       // resolve the wave chain right to left
-        for (int q = CM2_LWAVES - 1; q >= 0; --q) {
-            if (!s_flag[q] && s_accc[q + 1]) {
-                if (s_accc[q] == 0) {
-                    for (int e = 0; e < 4; ++e) s_acc[q][e] = s_acc[q + 1][e];
-                } else {
-                    for (int e = 0; e < 4; ++e) s_acc[q][e] = __fadd_rn(s_acc[q][e], s_acc[q + 1][e]);
-                }
-                s_accc[q] += s_accc[q + 1];
-            }
-        }
-    }
-    __syncthreads();
-    if (!flag) {
-        const Acc o = {s_acc[w + 1][0], s_acc[w + 1][1], s_acc[w + 1][2], s_acc[w + 1][3], s_accc[w + 1]};
-        if (S.c == 0) S = o; else if (o.c) acc_add(S, o);
-    }
-    Acc carry = acc_shfl_down(S, 1);
-    if (lane == 63) {
-        carry.x = s_acc[w + 1][0]; carry.y = s_acc[w + 1][1]; carry.z = s_acc[w + 1][2];
-        carry.i = s_acc[w + 1][3]; carry.c = s_accc[w + 1];
-    }
-    if (has_head && carry.c) acc_add(run, carry);
-
-    uint32_t nkeep = (has_head && run.c >= min_pts) ? 1u : 0u;
-#pragma unroll
-    for (int j = 0; j < CM2_LITEMS; ++j)
-        if ((fmask >> j & 1u) && fin[j].c >= min_pts) ++nkeep;
-    uint32_t tot;
-    const uint32_t local_slot = block_excl_scan_w<CM2_LWAVES>(nkeep, lds, &tot);
 
     // ---- output offset: kept voxels of every earlier tile (decoupled look-back, wave 0)
-    if (w == 0) {
+    if (dbg & 4u) { if (threadIdx.x == 0) s_off = 0; }
+    else if (w == 0) {
         uint32_t excl = 0;
         bool timed_out = false;
         for (int j = static_cast<int>(tile) - 1; j >= 0; j -= 64) {
@@ -768,22 +723,16 @@ __global__ __launch_bounds__(CM2_LBLOCK) void k2_local(const CmFrameDev* __restr
     const uint32_t tile_off = s_off;
     if (tile == n_lt - 1) report_state(host_state, st, CM_DEV_OK, tile_off + c_t, true);
 
-    uint32_t slot = tile_off + local_slot;
 #pragma unroll
-    for (int j = 0; j <= CM2_LITEMS; ++j) {
-        const bool is_last = (j == CM2_LITEMS);
-        const int jj = is_last ? 0 : j;
-        const bool emit = is_last ? (has_head && run.c >= min_pts) : ((fmask >> jj & 1u) && fin[jj].c >= min_pts);
-        if (emit) {
-            const Acc acc = is_last ? run : fin[jj];
-            const uint32_t ak = is_last ? run_key : fkey[jj];
-            const float c = static_cast<float>(acc.c);
+    for (int j = 0; j < LITEMS; ++j) {
+        if (vlen[j]) {
+            const uint32_t slot = tile_off + row_base[j];
+            const float c = static_cast<float>(acc[j].c);
             float4 o;
-            o.x = __fdiv_rn(acc.x, c); o.y = __fdiv_rn(acc.y, c);
-            o.z = __fdiv_rn(acc.z, c); o.w = __fdiv_rn(acc.i, c);
+            o.x = __fdiv_rn(acc[j].x, c); o.y = __fdiv_rn(acc[j].y, c);
+            o.z = __fdiv_rn(acc[j].z, c); o.w = __fdiv_rn(acc[j].i, c);
             out[slot] = o;
-            if (out_key) { out_key[slot] = ak + kbase; out_cnt[slot] = acc.c; }
-            ++slot;
+            if (out_key) { out_key[slot] = sk[si[vstart[j]]]; out_cnt[slot] = acc[j].c; }
         }
     }
 }
@@ -794,6 +743,7 @@ void cmk2_hist0(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t*
                 uint32_t* grp_clear_a, uint32_t* grp_clear_b, uint32_t n_group_words, uint32_t n_clear_a_words,
                 unsigned long long* tile_state, uint32_t n_tile_state, float* records, int grid_mode,
                 uint32_t shift0, uint32_t n_global_passes, uint32_t n_tiles) {
+    if (getenv("CM_DBG_NOGRP")) shift0 |= 0x100u;      // timing experiment only: wrong results
     hipLaunchKernelGGL(k2_hist0, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, st, hist, grp_acc, grp_clear_a, grp_clear_b,
                        n_group_words, n_clear_a_words, tile_state, n_tile_state, records, grid_mode, shift0,
                        n_global_passes);
@@ -817,8 +767,14 @@ void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, CmFrameState*
 }
 void cmk2_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next, uint32_t* host_state,
                 const void* rec, unsigned long long* tile_state, void* out, uint32_t* out_key, uint32_t* out_cnt,
-                uint32_t low_bits, uint32_t n_local_tiles) {
-    hipLaunchKernelGGL(k2_local, dim3(n_local_tiles), dim3(CM2_LBLOCK), 0, s, fd, st, st_next, host_state,
-                       reinterpret_cast<const float4*>(rec), tile_state, reinterpret_cast<float4*>(out), out_key,
-                       out_cnt, low_bits);
+                uint32_t low_bits, uint32_t n_padded, int variant) {
+    static const uint32_t dbg = getenv("CM_DBG") ? static_cast<uint32_t>(atoi(getenv("CM_DBG"))) : 0u;
+    const float4* r = reinterpret_cast<const float4*>(rec);
+    float4* o = reinterpret_cast<float4*>(out);
+    if (variant <= 1)
+        hipLaunchKernelGGL((k2_local<2048, 2816, 512>), dim3(n_padded / 2048), dim3(512), 0, s, fd, st, st_next, host_state,
+                           r, tile_state, o, out_key, out_cnt, low_bits, dbg);
+    else
+        hipLaunchKernelGGL((k2_local<4096, 5632, 1024>), dim3(n_padded / 4096), dim3(1024), 0, s, fd, st, st_next, host_state,
+                           r, tile_state, o, out_key, out_cnt, low_bits, dbg);
 }
