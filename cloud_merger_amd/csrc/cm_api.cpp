@@ -164,7 +164,8 @@ void quat_to_rows(const double q[4], const double t[3], float m[12]) {
 // Host copy of the kernels' grid guard for a box (the crop box, or bounds handed in): true when the box itself fits PCL's int32 index,
 // in which case the data min/max pass can be skipped (box-relative indices give the same
 // occupancy and the same order). Also returns the key width.
-bool box_grid(const float bmin[3], const float bmax[3], const float inv[3], uint32_t* key_bits) {
+bool box_grid(const float bmin[3], const float bmax[3], const float inv[3], uint32_t* key_bits,
+              int32_t* min_b = nullptr, int32_t* div_b = nullptr) {
     long long d[3];
     unsigned long long cells = 1;
     for (int a = 0; a < 3; ++a) {
@@ -175,6 +176,7 @@ bool box_grid(const float bmin[3], const float bmax[3], const float inv[3], uint
         const int hi = static_cast<int>(std::floor(bmax[a] * inv[a]));
         if (hi < lo) return false;
         cells *= static_cast<unsigned long long>(hi - lo + 1);
+        if (min_b) { min_b[a] = lo; div_b[a] = hi - lo + 1; }
     }
     if (d[0] * d[1] * d[2] > 2147483647LL || cells > 0xFFFFFFFFull) return false;
     uint32_t bits = 1;
@@ -494,14 +496,17 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
                 const int e = bootstrap_box(c);
                 if (e < 0) return e;
             }
-            if (c->pred_ok && box_grid(c->pred_min, c->pred_max, inv_leaf, &kb)) {
+            if (c->pred_ok && box_grid(c->pred_min, c->pred_max, inv_leaf, &kb, f.box_min_b, f.box_div_b)) {
                 gm = 2;
                 for (int a = 0; a < 3; ++a) { f.ext_min[a] = c->pred_min[a]; f.ext_max[a] = c->pred_max[a]; }
             } else {
                 c->pred_ok = false;
             }
         }
+        if (gm == 1 && !box_grid(p->crop_min, p->crop_max, inv_leaf, &kb, f.box_min_b, f.box_div_b)) gm = 0;
         if (gm != 0) {
+            f.box_key_bits = kb;
+            f.box_predicted = gm == 2 ? 1u : 0u;
             uint32_t g = 1 + (kb > CM2_MAX_LOW_BITS + 8 ? (kb - CM2_MAX_LOW_BITS - 1) / 8 : 0) + c->v2_extra_passes;
             if (g > 1 && 8 * (g - 1) >= kb) g = 0;           // nothing left for the local finish to add
             if (g >= 1 && g <= CM_MAX_PASSES) {

@@ -15,30 +15,42 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 struct Pt { float x, y, z, i; };
 
-__device__ __forceinline__ float load_f32_unaligned(const unsigned char* p) {
+// Sensor payloads live in HBM: say so, so the loads are global_load (vmcnt only), not flat_load.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CM_GLOBAL_AS __attribute__((address_space(1)))
+#else
+#define CM_GLOBAL_AS
+#endif
+typedef const CM_GLOBAL_AS unsigned char* cm_gptr;
+typedef float cm_v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float load_f32_unaligned(cm_gptr p) {
     float f;
-    __builtin_memcpy(&f, p, 4);
+    __builtin_memcpy(&f, (const void*)p, 4);
     return f;
 }
 
-__device__ __forceinline__ Pt load_point(const unsigned char* __restrict__ data, uint32_t layout,
+__device__ __forceinline__ Pt load_point(const unsigned char* __restrict__ data_generic, uint32_t layout,
                                          uint32_t step, uint32_t ox, uint32_t oy, uint32_t oz,
                                          uint32_t oi, uint32_t idx) {
+    cm_gptr data = (cm_gptr)data_generic;
+    typedef const CM_GLOBAL_AS cm_v4f* f4ptr;
+    typedef const CM_GLOBAL_AS float* f1ptr;
     Pt p;
     if (layout == CM_LAYOUT_XYZI16) {
-        const float4 v = *reinterpret_cast<const float4*>(data + static_cast<size_t>(idx) * 16);
+        const cm_v4f v = *(f4ptr)(data + static_cast<size_t>(idx) * 16);
         p.x = v.x; p.y = v.y; p.z = v.z; p.i = v.w;
     } else if (layout == CM_LAYOUT_PCL32) {
-        const unsigned char* q = data + static_cast<size_t>(idx) * 32;
-        const float4 v = *reinterpret_cast<const float4*>(q);
+        cm_gptr q = data + static_cast<size_t>(idx) * 32;
+        const cm_v4f v = *(f4ptr)q;
         p.x = v.x; p.y = v.y; p.z = v.z;
-        p.i = *reinterpret_cast<const float*>(q + 16);
+        p.i = *(f1ptr)(q + 16);
     } else {
-        const unsigned char* q = data + static_cast<size_t>(idx) * step;
+        cm_gptr q = data + static_cast<size_t>(idx) * step;
         p.x = load_f32_unaligned(q + ox);
         p.y = load_f32_unaligned(q + oy);
         p.z = load_f32_unaligned(q + oz);
-        p.i = (oi == 0xFFFFFFFFu) ? 0.0f : load_f32_unaligned(q + oi);
+        p.i = (oi == 0xFFFFFFFFu) ? 0.0f : load_f32_unaligned(q + ((oi == 0xFFFFFFFFu) ? 0u : oi));
     }
     return p;
 }
@@ -135,20 +147,29 @@ __device__ __forceinline__ uint32_t sensor_of_tile(const CmFrameDev* __restrict_
 // Tile loader: the 16 points a thread owns in its tile (wave-striped), every load issued before
 // the first use. Slots past the end of the cloud read as NaN and are never valid.
 // ------------------------------------------------------------------------------------------------
+// Branch-free: slots past the end of the cloud load the last point (a valid address) and are turned
+// into NaN afterwards, so the N loads go out back to back and the compute waits for them one by one.
 template <int LAYOUT, int N>
 __device__ __forceinline__ void load_tile_points(const CmSensorDev& sd, uint32_t first, Pt (&p)[N]) {
     const unsigned char* __restrict__ data = sd.data;
     const uint32_t n = sd.n, step = sd.point_step;
     const uint32_t ox = sd.off_x, oy = sd.off_y, oz = sd.off_z, oi = sd.off_i;
     const float nan = __uint_as_float(0x7FC00000u);
+    if (n == 0) {                                         // uniform; no tile belongs to an empty cloud anyway
+#pragma unroll
+        for (int r = 0; r < N; ++r) { p[r].x = nan; p[r].y = nan; p[r].z = nan; p[r].i = 0.f; }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < N; ++r) {
         const uint32_t i = first + r * 64;
-        if (i < n) {
-            p[r] = load_point(data, LAYOUT, step, ox, oy, oz, oi, i);
-        } else {
-            p[r].x = nan; p[r].y = nan; p[r].z = nan; p[r].i = 0.f;
-        }
+        p[r] = load_point(data, LAYOUT, step, ox, oy, oz, oi, i < n ? i : n - 1);
+    }
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        const bool ok = first + r * 64 < n;
+        p[r].x = ok ? p[r].x : nan; p[r].y = ok ? p[r].y : nan; p[r].z = ok ? p[r].z : nan;
+        p[r].i = ok ? p[r].i : 0.f;
     }
 }
 

@@ -69,6 +69,12 @@ struct CmFrameDev {
     uint32_t outlier_min_nb;
     float ext_min[3];         // grid bounds handed in by the host (fused cloud across GPUs: the
     float ext_max[3];         // min/max of the WHOLE merged cloud, all-reduced over the ranks)
+    // Bucket path: the grid of the box the frame is sorted in (crop box or predicted box), set up on the
+    // host with the arithmetic of compute_grid (cm_common.hpp): cell of the box minimum, cells per axis.
+    int32_t box_min_b[3];
+    int32_t box_div_b[3];
+    uint32_t box_key_bits;
+    uint32_t box_predicted;   // 1: the box is a prediction (check every point against it)
 };
 
 // Per-frame device state, zeroed before the first kernel of a frame.

@@ -71,8 +71,10 @@ struct BoxGrid {
     uint32_t mul1, mul2;
 };
 
-__device__ __forceinline__ BoxGrid box_grid_of(const CmFrameDev* __restrict__ fd, const int* min_b, const int* div_b) {
+__device__ __forceinline__ BoxGrid box_grid_of(const CmFrameDev* __restrict__ fd) {
     BoxGrid b;
+    const int32_t* min_b = fd->box_min_b;
+    const int32_t* div_b = fd->box_div_b;
     b.inv0 = fd->inv_leaf[0]; b.inv1 = fd->inv_leaf[1]; b.inv2 = fd->inv_leaf[2];
     b.fb0 = static_cast<float>(min_b[0]); b.fb1 = static_cast<float>(min_b[1]); b.fb2 = static_cast<float>(min_b[2]);
     b.d0 = div_b[0]; b.d1 = div_b[1]; b.d2 = div_b[2];
@@ -117,7 +119,6 @@ __global__ __launch_bounds__(CM2_BLOCK) void k2_hist0(const CmFrameDev* __restri
                                                       float* __restrict__ records,
                                                       int grid_mode, uint32_t shift0, uint32_t n_global_passes) {
     __shared__ uint32_t lh[CM_RADIX];
-    __shared__ float s_red[CM_WAVES][8];
     __shared__ float s_mm[CM2_WAVES][6];
     __shared__ uint32_t s_cnt[CM2_WAVES];
     __shared__ uint32_t s_out;
@@ -126,19 +127,19 @@ __global__ __launch_bounds__(CM2_BLOCK) void k2_hist0(const CmFrameDev* __restri
     for (uint32_t k = tile * CM2_BLOCK + threadIdx.x; k < n_clear_a_words; k += gridDim.x * CM2_BLOCK) grp_clear_a[k] = 0;
     for (uint32_t k = tile * CM2_BLOCK + threadIdx.x; k < n_tile_state; k += gridDim.x * CM2_BLOCK) tile_state[k] = 0ull;
 
-    Grid g;
-    compute_grid(fd, nullptr, 0, grid_mode, fd->inv_leaf, s_red, g);
-    if (tile == 0 && threadIdx.x == 0) {
-        st->status = g.status;
+    if (tile == 0 && threadIdx.x == 0) {                 // the box and its grid, as the host set them up
+        st->status = CM_DEV_OK;
         for (int a = 0; a < 3; ++a) {
-            st->min_p[a] = g.min_p[a]; st->max_p[a] = g.max_p[a];
-            st->min_b[a] = g.min_b[a]; st->max_b[a] = g.max_b[a]; st->div_b[a] = g.div_b[a];
+            st->min_p[a] = grid_mode == 2 ? fd->ext_min[a] : fd->crop_min[a];
+            st->max_p[a] = grid_mode == 2 ? fd->ext_max[a] : fd->crop_max[a];
+            st->min_b[a] = fd->box_min_b[a]; st->max_b[a] = fd->box_min_b[a] + fd->box_div_b[a] - 1;
+            st->div_b[a] = fd->box_div_b[a];
         }
-        st->key_bits = g.key_bits;
+        st->key_bits = fd->box_key_bits;
         st->n_passes = n_global_passes;
     }
-    if (g.status != CM_DEV_OK) return;
-    const BoxGrid b = box_grid_of(fd, g.min_b, g.div_b);
+    const BoxGrid b = box_grid_of(fd);
+    const bool predicted = grid_mode == 2;
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t slot0 = tile * CM_TILE + w * (64 * CM2_ITEMS) + lane;
@@ -164,33 +165,35 @@ __global__ __launch_bounds__(CM2_BLOCK) void k2_hist0(const CmFrameDev* __restri
         if (point_valid(x, y, z, crop, fd->crop_min, fd->crop_max)) {
             bool in;
             const uint32_t key = key_of(b, x, y, z, &in);
-            any_out = any_out || !in;
+            if (predicted) {                              // a crop box holds every valid point by construction
+                any_out = any_out || !in;
+                mn0 = fminf(mn0, x); mx0 = fmaxf(mx0, x);
+                mn1 = fminf(mn1, y); mx1 = fmaxf(mx1, y);
+                mn2 = fminf(mn2, z); mx2 = fmaxf(mx2, z);
+                ++cnt;
+            } else {
+                in = true;
+            }
             if (in) atomicAdd(&lh[(key >> shift0) & (CM_RADIX - 1)], 1u);
-            mn0 = fminf(mn0, x); mx0 = fmaxf(mx0, x);
-            mn1 = fminf(mn1, y); mx1 = fmaxf(mx1, y);
-            mn2 = fminf(mn2, z); mx2 = fmaxf(mx2, z);
-            ++cnt;
         }
     }
-    if (any_out) s_out = 1u;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        mn0 = fminf(mn0, __shfl_xor(mn0, d)); mx0 = fmaxf(mx0, __shfl_xor(mx0, d));
-        mn1 = fminf(mn1, __shfl_xor(mn1, d)); mx1 = fmaxf(mx1, __shfl_xor(mx1, d));
-        mn2 = fminf(mn2, __shfl_xor(mn2, d)); mx2 = fmaxf(mx2, __shfl_xor(mx2, d));
-        cnt += __shfl_xor(cnt, d);
-    }
-    if (lane == 0) {
-        s_mm[w][0] = mn0; s_mm[w][1] = mn1; s_mm[w][2] = mn2;
-        s_mm[w][3] = mx0; s_mm[w][4] = mx1; s_mm[w][5] = mx2;
-        s_cnt[w] = cnt;
+    if (predicted) {
+        if (any_out) s_out = 1u;
+        mn0 = wave_min_f32_l63(mn0); mn1 = wave_min_f32_l63(mn1); mn2 = wave_min_f32_l63(mn2);
+        mx0 = wave_max_f32_l63(mx0); mx1 = wave_max_f32_l63(mx1); mx2 = wave_max_f32_l63(mx2);
+        cnt = wave_sum_u32(cnt);
+        if (lane == 63) {
+            s_mm[w][0] = mn0; s_mm[w][1] = mn1; s_mm[w][2] = mn2;
+            s_mm[w][3] = mx0; s_mm[w][4] = mx1; s_mm[w][5] = mx2;
+            s_cnt[w] = cnt;
+        }
     }
     __syncthreads();
     if (threadIdx.x < CM_RADIX) {
         const uint32_t c = lh[threadIdx.x];
         hist[static_cast<size_t>(tile) * CM_RADIX + threadIdx.x] = c;
         if (c && !(shift0 & 0x100u)) atomicAdd(&grp_acc[static_cast<size_t>(tile / CM_GROUP) * CM_RADIX + threadIdx.x], c);
-    } else if (threadIdx.x < CM_RADIX + 8) {         // record: min xyz, max xyz, count, pad
+    } else if (predicted && threadIdx.x < CM_RADIX + 8) {         // record: min xyz, max xyz, count, pad
         const int k = threadIdx.x - CM_RADIX;
         float v = 0.f;
         if (k < 6) {
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(CM2_BLOCK) void k2_hist(const CmFrameState* __restr
 // selected after the device probe passed).
 // ------------------------------------------------------------------------------------------------
 template <bool FIRST>
-__global__ __launch_bounds__(CM2_BLOCK, 2) void k2_scatter(const CmFrameDev* __restrict__ fd,
+__global__ __launch_bounds__(CM2_BLOCK, 3) void k2_scatter(const CmFrameDev* __restrict__ fd,
                                                            CmFrameState* __restrict__ st,
                                                            const float4* __restrict__ rec_in,
                                                            float4* __restrict__ rec_out,
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 2) void k2_scatter(const CmFrameDev* __r
                                                            uint32_t n_groups, uint32_t n_padded,
                                                            const float* __restrict__ records,
                                                            uint32_t n_records, int fold) {
-    __shared__ float4 srec[CM_TILE];
+    __shared__ float4 srec[CM_TILE / 2];                // staging in two halves: 41 KB per workgroup, three per CU
     __shared__ uint32_t whist[CM2_WAVES][CM_RADIX];
     __shared__ uint32_t gofs[CM_RADIX];
     __shared__ uint32_t lds[CM2_WAVES];
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 2) void k2_scatter(const CmFrameDev* __r
         const uint32_t per = gridDim.x / 8;              // contiguous tile range per XCD (see k_scatter)
         if (blockIdx.x < per * 8) tile = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
     }
-    const BoxGrid b = box_grid_of(fd, st->min_b, st->div_b);
+    const BoxGrid b = box_grid_of(fd);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t first = tile * CM_TILE + w * (64 * CM2_ITEMS) + lane;
 
@@ -368,24 +371,35 @@ __global__ __launch_bounds__(CM2_BLOCK, 2) void k2_scatter(const CmFrameDev* __r
         }
     }
     __syncthreads();
+    const uint32_t tile_valid = s_tile_valid;
+    uint32_t lpos[CM2_ITEMS];
 #pragma unroll
     for (int r = 0; r < CM2_ITEMS; ++r) {
-        if (vmask >> r & 1u) {
-            const uint32_t digit = (key[r] >> shift) & (CM_RADIX - 1);
-            srec[whist[w][digit] + rank[r]] = rec[r];
-        }
+        const uint32_t digit = (key[r] >> shift) & (CM_RADIX - 1);
+        lpos[r] = (vmask >> r & 1u) ? whist[w][digit] + rank[r] : 0xFFFFFFFFu;
     }
-    __syncthreads();
-    const uint32_t tile_valid = s_tile_valid;
+    // Two rounds through the staging buffer: sorted positions [0, 2048), then [2048, 4096).
 #pragma unroll
-    for (int j = 0; j < CM2_ITEMS; ++j) {
-        const uint32_t t = j * CM2_BLOCK + threadIdx.x;
-        if (t < tile_valid) {
-            const float4 r4 = srec[t];
-            const uint32_t k = key_of(b, r4);
-            const uint32_t pos = gofs[(k >> shift) & (CM_RADIX - 1)] + t;
-            rec_out[pos] = r4;
-            if (next_shift < 32u) dig_out[pos] = static_cast<unsigned char>((k >> next_shift) & 0xFFu);
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t lo = h * (CM_TILE / 2);
+        if (h == 1) {
+            if (tile_valid <= lo) break;                   // uniform
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < CM2_ITEMS; ++r)
+            if (lpos[r] - lo < CM_TILE / 2) srec[lpos[r] - lo] = rec[r];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < CM2_ITEMS / 2; ++j) {
+            const uint32_t t = lo + j * CM2_BLOCK + threadIdx.x;
+            if (t < tile_valid) {
+                const float4 r4 = srec[t - lo];
+                const uint32_t k = key_of(b, r4);
+                const uint32_t pos = gofs[(k >> shift) & (CM_RADIX - 1)] + t;
+                rec_out[pos] = r4;
+                if (next_shift < 32u) dig_out[pos] = static_cast<unsigned char>((k >> next_shift) & 0xFFu);
+            }
         }
     }
 
@@ -459,6 +473,7 @@ __global__ __launch_bounds__(LBLOCK) void k2_local(const CmFrameDev* __restrict_
     __shared__ uint32_t sk[LCAP];                      // key of every slot
     __shared__ uint16_t si[LCAP];                      // slots in sorted order
     __shared__ uint32_t whist[LWAVES][HWORDS];         // digit counts per wave; after the sort: head positions
+    __shared__ uint16_t dbase[BINS];                   // first sorted position of every digit
     __shared__ uint32_t lds[LWAVES];
     __shared__ uint32_t s_a, s_keyprev, s_off;
     uint16_t* hpos = reinterpret_cast<uint16_t*>(&whist[0][0]);
@@ -478,7 +493,7 @@ __global__ __launch_bounds__(LBLOCK) void k2_local(const CmFrameDev* __restrict_
     }
     const uint32_t n_lt = (n + LT - 1) / LT;
     if (tile >= n_lt) return;
-    const BoxGrid b = box_grid_of(fd, st->min_b, st->div_b);
+    const BoxGrid b = box_grid_of(fd);
     const uint32_t L = low_bits;
     const uint32_t min_pts = fd->min_pts > 1 ? fd->min_pts : 1u;
 
@@ -593,16 +608,15 @@ __global__ __launch_bounds__(LBLOCK) void k2_local(const CmFrameDev* __restrict_
             uint32_t all;
             const uint32_t db = block_excl_scan_w<LWAVES>(t0 + t1, lds, &all);
             if (threadIdx.x < HWORDS) {
-                const uint32_t add = db | ((db + t0) << 16);
-#pragma unroll
-                for (int q = 0; q < LWAVES; ++q) whist[q][threadIdx.x] += add;
+                dbase[2 * threadIdx.x] = static_cast<uint16_t>(db);
+                dbase[2 * threadIdx.x + 1] = static_cast<uint16_t>(db + t0);
             }
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < LITEMS; ++r) {
                 const uint32_t e = w * (64 * LITEMS) + r * 64 + lane;
                 if (e < m) {
-                    const uint32_t pos = ((whist[w][dg[r] >> 1] >> ((dg[r] & 1u) * 16u)) & 0xFFFFu) + rk[r];
+                    const uint32_t pos = dbase[dg[r]] + ((whist[w][dg[r] >> 1] >> ((dg[r] & 1u) * 16u)) & 0xFFFFu) + rk[r];
                     si[pos] = ei[r];
                 }
             }
@@ -636,33 +650,27 @@ __global__ __launch_bounds__(LBLOCK) void k2_local(const CmFrameDev* __restrict_
     __syncthreads();
 
     // ---- kept voxels (A.4 step 7: at least min_pts points), published at once for the look-back
+    // Thread t takes voxels [6t, 6t+6): a wave covers 384 consecutive voxels (similar run lengths), and
+    // the kept ones get consecutive output slots from one scan.
     uint32_t vstart[LITEMS], vlen[LITEMS];
     uint32_t nkeep = 0;
+    {
+        const uint32_t v0 = threadIdx.x * LITEMS;
+        uint32_t hp = (v0 < n_vox) ? hpos[v0] : m;
 #pragma unroll
-    for (int j = 0; j < LITEMS; ++j) {
-        const uint32_t v = j * LBLOCK + threadIdx.x;               // consecutive voxels in a wave: similar run lengths
-        vstart[j] = 0; vlen[j] = 0;
-        if (v < n_vox) {
-            vstart[j] = hpos[v];
-            vlen[j] = ((v + 1 < n_vox) ? hpos[v + 1] : m) - vstart[j];
-            if (vlen[j] < min_pts) vlen[j] = 0;
-            nkeep += vlen[j] ? 1u : 0u;
+        for (int j = 0; j < LITEMS; ++j) {
+            const uint32_t v = v0 + j;
+            vstart[j] = hp; vlen[j] = 0;
+            if (v < n_vox) {
+                const uint32_t nx = (v + 1 < n_vox) ? hpos[v + 1] : m;
+                vlen[j] = (nx - hp >= min_pts) ? nx - hp : 0u;
+                nkeep += vlen[j] ? 1u : 0u;
+                hp = nx;
+            }
         }
     }
-    // Output slots must follow voxel order: voxel v = j * LBLOCK + t, so scan per j-row.
-    uint32_t row_base[LITEMS];
-    uint32_t c_t = 0;
-#pragma unroll
-    for (int j = 0; j < LITEMS; ++j) {
-        uint32_t tot = 0;
-        if (static_cast<uint32_t>(j) * LBLOCK < n_vox) {           // uniform
-            const uint32_t ex = block_excl_scan_w<LWAVES>(vlen[j] ? 1u : 0u, lds, &tot);
-            row_base[j] = c_t + ex;
-        } else {
-            row_base[j] = 0;
-        }
-        c_t += tot;
-    }
+    uint32_t c_t;
+    const uint32_t my_slot = block_excl_scan_w<LWAVES>(nkeep, lds, &c_t);
     if (threadIdx.x == 0) {
         const unsigned long long v = (tile == 0 ? CM2_FLAG_PREFIX : CM2_FLAG_AGG) | c_t;
         __hip_atomic_store(&tile_state[tile], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -723,16 +731,17 @@ __global__ __launch_bounds__(LBLOCK) void k2_local(const CmFrameDev* __restrict_
     const uint32_t tile_off = s_off;
     if (tile == n_lt - 1) report_state(host_state, st, CM_DEV_OK, tile_off + c_t, true);
 
+    uint32_t slot = tile_off + my_slot;
 #pragma unroll
     for (int j = 0; j < LITEMS; ++j) {
         if (vlen[j]) {
-            const uint32_t slot = tile_off + row_base[j];
             const float c = static_cast<float>(acc[j].c);
             float4 o;
             o.x = __fdiv_rn(acc[j].x, c); o.y = __fdiv_rn(acc[j].y, c);
             o.z = __fdiv_rn(acc[j].z, c); o.w = __fdiv_rn(acc[j].i, c);
             out[slot] = o;
             if (out_key) { out_key[slot] = sk[si[vstart[j]]]; out_cnt[slot] = acc[j].c; }
+            ++slot;
         }
     }
 }
