@@ -166,7 +166,11 @@ def main():
                    "min_points_per_voxel": args.min_pts, "sharding": f"frame-sharded x{world}, no collective",
                    "inputs": "resident in HBM (16-byte XYZI records)",
                    "frames_in_flight": inflight,
-                   "radix_ranking": "lds-add (device probe passed)" if res.path_flags & 1 else "ballot-match"},
+                   "radix_ranking": "lds-add (device probe passed)" if res.path_flags & 1 else "ballot-match",
+                   "path": ("bucket path (cm_kernels_v2.hip): %d global passes over point records + LDS-local finish; box %s"
+                            % (res.sort_passes, "predicted from the previous frame's bounds" if res.path_flags & 4 else "= crop box"))
+                           if res.path_flags & 2 else
+                           "general path (cm_kernels.hip): %d-pass LSD sort of (voxel, point) pairs + gather" % res.sort_passes},
     }
 
     if rank == 0:
@@ -206,13 +210,14 @@ def main():
         # be read from inside the process). gfx950's FETCH_SIZE counts wide reads at half their
         # bytes, so the corrected figure (fetch x2 + write) is quoted; raw kept beside it.
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", f"r1_pmc_traffic_cfg{args.config}_minpts{args.min_pts}.json")
+        suffix = "_bucket" if res.path_flags & 2 else ""
+        tpath = os.path.join(ROOT, "profiles", f"r1_pmc_traffic_cfg{args.config}_minpts{args.min_pts}{suffix}.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             traffic = tj["traffic_high"]
             traffic_src = {"file": os.path.relpath(tpath, ROOT), "fetch_raw": tj["fetch_raw"], "write": tj["write"],
                            "fetch_corrected_x2": tj["fetch_x2"], "frames_averaged": tj["frames"]}
-        # The path is a sequence of ~11 dependent launches per frame, so the roofline is quoted for
+        # The path is a sequence of 5 (bucket path) to 11 dependent launches per frame, so the roofline is quoted for
         # the frame: algorithmic bytes (16*N_in + 16*M) over the time a frame takes in
         # the timed region above (independent frames overlap on separate streams).
         achieved = b_alg * args.steps / elapsed / 1e9

@@ -622,6 +622,7 @@ int wait_frame(cm_ctx* c, cm_result* res) {
     } else {
         HIP_TRY(c, hipEventSynchronize(c->ev_done));
         c->in_flight.store(false);
+        bool redone = false;
         if (c->last_v2) {
             // The bucket path hands a frame back when a point lay outside the predicted box, when a
             // bucket did not fit LDS, or when a workgroup gave up waiting for its predecessors: the
@@ -632,6 +633,7 @@ int wait_frame(cm_ctx* c, cm_result* res) {
                 if (h0.err == CM_DEV_ERR_BUCKET && c->v2_extra_passes < CM_MAX_PASSES) ++c->v2_extra_passes;
                 if (h0.err == CM_DEV_ERR_LOOKBACK) c->v2_off_frames = 0xFFFFFFFFu;
                 ++c->n_redone;
+                redone = true;
                 c->prof_used = 0;
                 c->last_v2 = false;
                 c->last_predicted = false;
@@ -676,7 +678,7 @@ int wait_frame(cm_ctx* c, cm_result* res) {
         }
         r.key_bits = h.key_bits;
         r.sort_passes = h.n_passes;
-        r.path_flags = (c->lds_rank ? 1u : 0u) | (c->last_v2 ? 2u : 0u) | (c->last_predicted ? 4u : 0u);
+        r.path_flags = (c->lds_rank ? 1u : 0u) | (c->last_v2 ? 2u : 0u) | (c->last_predicted ? 4u : 0u) | (redone ? 8u : 0u);
         if (c->last_predicted && h.status == CM_OK) {
             // The device sorted by cells of the predicted box (same order); the grid PCL itself would
             // report comes from the cloud's exact bounds, which the frame also produced (A.4 steps 2, 4).

@@ -26,7 +26,6 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "cm_common.hpp"
 #include "cm_device.h"
@@ -94,6 +93,16 @@ __device__ __forceinline__ uint32_t key_of(const BoxGrid& b, float x, float y, f
 __device__ __forceinline__ uint32_t key_of(const BoxGrid& b, const float4& r) {
     bool in;
     return key_of(b, r.x, r.y, r.z, &in);
+}
+
+// x / c for a point count c (an integer below 2^16) given rc = RN(1/c): quotient estimate, exact
+// residual by FMA, one correction — the correctly rounded x / c that pcl::VoxelGrid's float division
+// gives (A.4 step 6) whenever x / c is a normal number; inf / NaN sums pass through unchanged.
+__device__ __forceinline__ float div_by_count(float x, float c, float rc) {
+    const float q = __fmul_rn(x, rc);
+    const float r = __fmaf_rn(-q, c, x);
+    const float q2 = __fmaf_rn(r, rc, q);
+    return finite_f32(q) ? q2 : q;
 }
 
 __device__ __forceinline__ uint32_t sensor_of_slot(const CmFrameDev* __restrict__ fd, uint32_t first) {
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(CM2_BLOCK) void k2_hist0(const CmFrameDev* __restri
     if (threadIdx.x < CM_RADIX) {
         const uint32_t c = lh[threadIdx.x];
         hist[static_cast<size_t>(tile) * CM_RADIX + threadIdx.x] = c;
-        if (c && !(shift0 & 0x100u)) atomicAdd(&grp_acc[static_cast<size_t>(tile / CM_GROUP) * CM_RADIX + threadIdx.x], c);
+        if (c) atomicAdd(&grp_acc[static_cast<size_t>(tile / CM_GROUP) * CM_RADIX + threadIdx.x], c);
     } else if (predicted && threadIdx.x < CM_RADIX + 8) {         // record: min xyz, max xyz, count, pad
         const int k = threadIdx.x - CM_RADIX;
         float v = 0.f;
@@ -465,7 +474,7 @@ __global__ __launch_bounds__(LBLOCK) void k2_local(const CmFrameDev* __restrict_
                                                        float4* __restrict__ out,
                                                        uint32_t* __restrict__ out_key,
                                                        uint32_t* __restrict__ out_cnt,
-                                                       uint32_t low_bits, uint32_t dbg) {
+                                                       uint32_t low_bits) {
     constexpr int LWAVES = LBLOCK / 64, LITEMS = (LCAP + LBLOCK - 1) / LBLOCK, EXT0 = LBLOCK < 256 ? LBLOCK : 256;
     constexpr int BINS = 1024, HWORDS = BINS / 2;          // two 16-bit counters per LDS word
     static_assert(LT == 4 * LBLOCK && LCAP <= 0xFFFF && HWORDS <= LBLOCK && LWAVES * HWORDS * 2 >= LCAP, "tile geometry");
@@ -569,10 +578,9 @@ __global__ __launch_bounds__(LBLOCK) void k2_local(const CmFrameDev* __restrict_
         const uint32_t kbase = (sk[a] >> L) << L;
         const unsigned long long span = static_cast<unsigned long long>(h_last - (sk[a] >> L) + 1u) << L;
         const uint32_t nb = span > 1ull ? 64u - static_cast<uint32_t>(__builtin_clzll(span - 1ull)) : 0u;
-        uint32_t npass = nb ? (nb + 9u) / 10u : 1u;
+        const uint32_t npass = nb ? (nb + 9u) / 10u : 1u;
         const uint32_t width = nb ? (nb + npass - 1u) / npass : 0u;
         const uint32_t dmask = (1u << width) - 1u;
-        if (dbg & 1u) npass = 1;
         for (uint32_t p = 0; p < npass; ++p) {
             uint32_t dg[LITEMS], rk[LITEMS];
             uint16_t ei[LITEMS];
@@ -671,12 +679,53 @@ __global__ __launch_bounds__(LBLOCK) void k2_local(const CmFrameDev* __restrict_
     }
     uint32_t c_t;
     const uint32_t my_slot = block_excl_scan_w<LWAVES>(nkeep, lds, &c_t);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == (LWAVES - 1) * 64) {              // the lane that later publishes the prefix: same-address stores stay in order
         const unsigned long long v = (tile == 0 ? CM2_FLAG_PREFIX : CM2_FLAG_AGG) | c_t;
         __hip_atomic_store(&tile_state[tile], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (dbg & 2u) return;
-
+    // ---- output offset: kept voxels of every earlier tile (decoupled look-back). The last wave does
+    // it while the others add up their voxels: it has the fewest voxels (often none), and what it waits for —
+    // the counts of the tiles before this one — is being published in the meantime.
+    if (w == LWAVES - 1) {
+        uint32_t excl = 0;
+        bool timed_out = false, done = false;
+        // Eight wave-wide reads (512 predecessors: a whole generation of resident tiles) go out together, so
+        // the walk back to the nearest published prefix usually costs one memory latency, not eight.
+        constexpr int LB = 8;
+        for (int j0 = static_cast<int>(tile) - 1; j0 >= 0 && !done; j0 -= 64 * LB) {
+            unsigned long long v[LB];
+#pragma unroll
+            for (int k = 0; k < LB; ++k) {
+                const int jj = j0 - 64 * k - lane;
+                v[k] = jj >= 0 ? __hip_atomic_load(&tile_state[jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                               : CM2_FLAG_PREFIX;              // before tile 0: an empty prefix
+            }
+#pragma unroll
+            for (int k = 0; k < LB; ++k) {
+                if (!done) {                                   // wave-uniform
+                    const int jj = j0 - 64 * k - lane;
+                    uint32_t spins = 0;
+                    while (!(v[k] >> 32) && spins < (1u << 18)) {
+                        __builtin_amdgcn_s_sleep(2);
+                        v[k] = __hip_atomic_load(&tile_state[jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ++spins;
+                    }
+                    if (!(v[k] >> 32)) { timed_out = true; v[k] = CM2_FLAG_PREFIX; }
+                    const unsigned long long pm = __ballot((v[k] & CM2_FLAG_PREFIX) != 0);
+                    const int first_p = pm ? __builtin_ctzll(pm) : 64;     // nearest predecessor with a full prefix
+                    excl += wave_sum_u32((lane <= first_p) ? static_cast<uint32_t>(v[k]) : 0u);
+                    done = pm != 0;
+                }
+            }
+        }
+        if (lane == 0) {
+            if (tile > 0)
+                __hip_atomic_store(&tile_state[tile], CM2_FLAG_PREFIX | static_cast<unsigned long long>(excl + c_t),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_off = excl;
+        }
+        if (__ballot(timed_out) && lane == 0) host_state[offsetof(CmFrameState, err) / 4] = CM_DEV_ERR_LOOKBACK;
+    }
     // ---- centroid sums: one lane per kept voxel adds its points in sorted (= stable) order, the
     // order pcl::VoxelGrid itself adds them in (A.4 step 6).
     Acc acc[LITEMS];
@@ -694,39 +743,6 @@ __global__ __launch_bounds__(LBLOCK) void k2_local(const CmFrameDev* __restrict_
         }
     }
 
-    // ---- output offset: kept voxels of every earlier tile (decoupled look-back, wave 0)
-    if (dbg & 4u) { if (threadIdx.x == 0) s_off = 0; }
-    else if (w == 0) {
-        uint32_t excl = 0;
-        bool timed_out = false;
-        for (int j = static_cast<int>(tile) - 1; j >= 0; j -= 64) {
-            const int jj = j - lane;
-            unsigned long long v = CM2_FLAG_PREFIX;             // lanes before tile 0: an empty prefix
-            if (jj >= 0) {
-                uint32_t spins = 0;
-                do {
-                    v = __hip_atomic_load(&tile_state[jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (v >> 32) break;
-                    __builtin_amdgcn_s_sleep(2);
-                } while (++spins < (1u << 18));
-                if (!(v >> 32)) { timed_out = true; v = CM2_FLAG_PREFIX; }
-            }
-            const unsigned long long pm = __ballot((v & CM2_FLAG_PREFIX) != 0);
-            const int first_p = pm ? __builtin_ctzll(pm) : 64;         // nearest predecessor with a full prefix
-            uint32_t val = (lane <= first_p) ? static_cast<uint32_t>(v) : 0u;
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) val += __shfl_xor(val, d);
-            excl += val;
-            if (pm) break;
-        }
-        if (lane == 0) {
-            if (tile > 0)
-                __hip_atomic_store(&tile_state[tile], CM2_FLAG_PREFIX | static_cast<unsigned long long>(excl + c_t),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_off = excl;
-        }
-        if (__ballot(timed_out) && lane == 0) host_state[offsetof(CmFrameState, err) / 4] = CM_DEV_ERR_LOOKBACK;
-    }
     __syncthreads();
     const uint32_t tile_off = s_off;
     if (tile == n_lt - 1) report_state(host_state, st, CM_DEV_OK, tile_off + c_t, true);
@@ -736,9 +752,10 @@ __global__ __launch_bounds__(LBLOCK) void k2_local(const CmFrameDev* __restrict_
     for (int j = 0; j < LITEMS; ++j) {
         if (vlen[j]) {
             const float c = static_cast<float>(acc[j].c);
+            const float rc = __frcp_rn(c);                  // RN(1/c), shared by the four quotients
             float4 o;
-            o.x = __fdiv_rn(acc[j].x, c); o.y = __fdiv_rn(acc[j].y, c);
-            o.z = __fdiv_rn(acc[j].z, c); o.w = __fdiv_rn(acc[j].i, c);
+            o.x = div_by_count(acc[j].x, c, rc); o.y = div_by_count(acc[j].y, c, rc);
+            o.z = div_by_count(acc[j].z, c, rc); o.w = div_by_count(acc[j].i, c, rc);
             out[slot] = o;
             if (out_key) { out_key[slot] = sk[si[vstart[j]]]; out_cnt[slot] = acc[j].c; }
             ++slot;
@@ -752,7 +769,6 @@ void cmk2_hist0(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t*
                 uint32_t* grp_clear_a, uint32_t* grp_clear_b, uint32_t n_group_words, uint32_t n_clear_a_words,
                 unsigned long long* tile_state, uint32_t n_tile_state, float* records, int grid_mode,
                 uint32_t shift0, uint32_t n_global_passes, uint32_t n_tiles) {
-    if (getenv("CM_DBG_NOGRP")) shift0 |= 0x100u;      // timing experiment only: wrong results
     hipLaunchKernelGGL(k2_hist0, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, st, hist, grp_acc, grp_clear_a, grp_clear_b,
                        n_group_words, n_clear_a_words, tile_state, n_tile_state, records, grid_mode, shift0,
                        n_global_passes);
@@ -777,13 +793,12 @@ void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, CmFrameState*
 void cmk2_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next, uint32_t* host_state,
                 const void* rec, unsigned long long* tile_state, void* out, uint32_t* out_key, uint32_t* out_cnt,
                 uint32_t low_bits, uint32_t n_padded, int variant) {
-    static const uint32_t dbg = getenv("CM_DBG") ? static_cast<uint32_t>(atoi(getenv("CM_DBG"))) : 0u;
     const float4* r = reinterpret_cast<const float4*>(rec);
     float4* o = reinterpret_cast<float4*>(out);
     if (variant <= 1)
         hipLaunchKernelGGL((k2_local<2048, 2816, 512>), dim3(n_padded / 2048), dim3(512), 0, s, fd, st, st_next, host_state,
-                           r, tile_state, o, out_key, out_cnt, low_bits, dbg);
+                           r, tile_state, o, out_key, out_cnt, low_bits);
     else
         hipLaunchKernelGGL((k2_local<4096, 5632, 1024>), dim3(n_padded / 4096), dim3(1024), 0, s, fd, st, st_next, host_state,
-                           r, tile_state, o, out_key, out_cnt, low_bits, dbg);
+                           r, tile_state, o, out_key, out_cnt, low_bits);
 }

@@ -95,11 +95,20 @@ typedef struct cm_result {
     uint32_t bounds_from_crop;     /* 1: grid origin taken from the crop box (same occupancy and
                                       order; the data min/max pass was skipped) */
     uint32_t key_bits;             /* bits of the linear voxel index */
-    uint32_t sort_passes;          /* 8-bit radix passes run */
-    uint32_t path_flags;           /* bit 0: radix ranking by lane-ordered LDS adds (the device probe at
-                                      cm_create passed); otherwise ballot matching */
+    uint32_t sort_passes;          /* 8-bit radix passes over the whole frame that were run */
+    uint32_t path_flags;           /* CM_PATH_* bits: how the frame was computed (same results either way) */
     float device_ms;               /* first kernel start -> last kernel end (CM_FLAG_PROFILE) */
 } cm_result;
+
+#define CM_PATH_LDS_RANK 1u    /* radix ranking by lane-ordered LDS adds (device probe at cm_create passed);
+                                  otherwise ballot matching */
+#define CM_PATH_BUCKET 2u      /* bucket path: point records sorted by the high index bits in sort_passes
+                                  passes, the rest finished per bucket inside LDS (needs a box before the
+                                  first point is read: the crop box or a predicted one) */
+#define CM_PATH_PREDICTED 4u   /* ... the box was the previous frame's bounds plus a margin; every point was
+                                  checked against it, min_b/max_b/div_b/min_p/max_p are the cloud's own */
+#define CM_PATH_REDONE 8u      /* the bucket path gave the frame back (a point outside the predicted box, or a
+                                  bucket too large for LDS) and the general path computed it */
 
 #define CM_MAX_STAGES 48
 typedef struct cm_stage_times {

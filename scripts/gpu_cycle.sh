@@ -19,6 +19,6 @@ for n in ("bench","bench_mp0"):
 rows=list(csv.DictReader(open("gpurun_out/${TAG}_kernel_stats.csv")))
 for r in rows[:14]:
     import re
-    m=re.search(r"(k_\w+(<\w+>)?|__amd\w+)", r["Name"]); nm=m.group(1) if m else r["Name"][:30]
+    m=re.search(r"(k2?_\w+(<[\w, ]+>)?|__amd\w+)", r["Name"]); nm=m.group(1) if m else r["Name"][:30]
     print("%-28s calls %5s avg_us %8.2f total_us_per_frame %8.2f"%(nm, r["Calls"], float(r["AverageNs"])/1e3, float(r["TotalDurationNs"])/1e3/77))
 PY

@@ -8,6 +8,6 @@ python3 - "$f" <<'PY'
 import csv,sys,re,json
 d=json.load(open("gpurun_out/ks.json")); print("ms/step %.4f alone t_dev %.4f"%(d["ms_per_step"], d["roofline"]["one_frame_alone"]["t_device_ms"]))
 for r in csv.DictReader(open(sys.argv[1])):
-    m=re.search(r"(k_\w+(<[\w, ]+>)?)", r["Name"])
+    m=re.search(r"(k2?_\w+(<[\w, ]+>)?)", r["Name"])
     if m and "probe" not in m.group(1) and "setup" not in m.group(1): print("%-26s calls %4s avg_us %7.2f"%(m.group(1), r["Calls"], float(r["AverageNs"])/1e3))
 PY

@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/${TAG}_$C
   timeout -k 10 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/${TAG}_$C -- \
-      python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --profile-frames 2 > gpurun_out/${TAG}_$C.json 2> gpurun_out/${TAG}_$C.err || { tail -5 gpurun_out/${TAG}_$C.err; exit 1; }
+      python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --profile-frames 2 --min-pts ${MP:-2} > gpurun_out/${TAG}_$C.json 2> gpurun_out/${TAG}_$C.err || { tail -5 gpurun_out/${TAG}_$C.err; exit 1; }
 done
 python3 - "$TAG" <<'PY'
 import csv, glob, json, re, sys, collections
@@ -18,19 +18,19 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     per = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
         if r.get("Counter_Name") != c: continue
-        m = re.search(r"(k_\w+)", r["Kernel_Name"])
+        m = re.search(r"(k2?_\w+)", r["Kernel_Name"])
         if not m: continue
         per[m.group(1)][0] += float(r["Counter_Value"]); per[m.group(1)][1] += 1
     res[c] = {k: {"sum_kb": v[0], "dispatches": v[1]} for k, v in per.items()}
 bench = json.load(open(f"gpurun_out/{tag}_FETCH_SIZE.json"))
-frames = res["FETCH_SIZE"]["k_keys"]["dispatches"]
+frames = max(res["FETCH_SIZE"].get("k_keys", {"dispatches": 0})["dispatches"], res["FETCH_SIZE"].get("k2_local", {"dispatches": 0})["dispatches"])
 out = {"frames": frames, "unit": "bytes per frame", "kernels": {},
        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KB -> bytes). gfx950 FETCH_SIZE "
                "counts wide coalesced reads at half their bytes (MI355X_MICROARCH.md): 'fetch_x2' doubles it; narrower "
                "accesses are uncalibrated, so the true figure lies between raw and x2."}
 tot_f = tot_w = 0.0
 for k in sorted(set(res["FETCH_SIZE"]) | set(res["WRITE_SIZE"])):
-    if k in ("k_probe_lds_order", "k_setup"): continue
+    if k in ("k_probe_lds_order", "k_setup") or res["FETCH_SIZE"].get(k, {"dispatches": 0})["dispatches"] < frames // 2: continue   # one-off kernels (probe, bootstrap)
     f = res["FETCH_SIZE"].get(k, {"sum_kb": 0})["sum_kb"] * 1024 / frames
     w = res["WRITE_SIZE"].get(k, {"sum_kb": 0})["sum_kb"] * 1024 / frames
     out["kernels"][k] = {"fetch_raw": f, "fetch_x2": 2 * f, "write": w}

@@ -24,7 +24,7 @@ def sort_path(request, monkeypatch):
     return request.param
 
 
-BUCKET, PREDICTED = 2, 4          # cm_result.path_flags
+BUCKET, PREDICTED, REDONE = 2, 4, 8          # cm_result.path_flags (CM_PATH_*)
 
 STATUS = {"OK": capi.OK, "EMPTY_INPUT": capi.EMPTY_INPUT, "GRID_OVERFLOW": capi.GRID_OVERFLOW}
 
@@ -546,3 +546,68 @@ def test_randomized_differential(seed):
         assert_centroids_close(g["out"], xyzi_of(out))
     elif st == oracle.GRID_OVERFLOW:
         assert same_bits(g["out"], xyzi_of(out))
+
+
+# ---- bucket path: predicted box, hand-back to the general path ---------------------------------
+def test_predicted_box_miss_is_redone_and_learned(sort_path):
+    """No crop box: the bucket path sorts in the previous frame's bounds plus a margin. A frame whose
+    cloud leaves that box is found out on the device, redone by the general path (same answer), and
+    the box follows."""
+    rng = np.random.default_rng(5)
+    near = [xyzi_cloud(rng.uniform(-5, 5, (40_000, 3)), rng.uniform(0, 100, 40_000))]
+    far = [xyzi_cloud(rng.uniform(-40, 60, (40_000, 3)), rng.uniform(0, 100, 40_000))]
+    params = MergeParams(leaf=(0.2,) * 3, min_points_per_voxel=0)
+    with capi.CloudMerger(max_points_total=40_000, max_sensors=1, flags=capi.FLAG_OCCUPANCY) as cm:
+        flags = []
+        for sensors in (near, near, far, far, near):
+            g = run_gpu(sensors, params, want_merged=False, cm=cm)
+            st, _, out, rep = oracle.merge_voxelize(sensors, params, stable=True)
+            assert g["res"].status == st == capi.OK and g["res"].n_out == rep.n_out
+            assert np.array_equal(g["cells"], rep.cells) and np.array_equal(g["counts"], rep.counts)
+            assert list(g["res"].min_b) == list(rep.min_b) and list(g["res"].div_b) == list(rep.div_b)
+            assert_centroids_close(g["out"], xyzi_of(out))
+            flags.append(g["res"].path_flags & (BUCKET | PREDICTED | REDONE))
+    if sort_path == "classic":
+        assert flags == [0] * 5
+    else:
+        bp = BUCKET | PREDICTED
+        assert flags == [bp, bp, REDONE, bp, bp]        # the far cloud leaves the box once; the near one fits the wider box
+
+
+def test_bucket_too_large_for_lds_is_redone(sort_path):
+    """5000 points in one voxel among sparse ones: that bucket cannot be finished inside LDS; the frame
+    goes back to the general path, and later frames sort more bits globally."""
+    rng = np.random.default_rng(6)
+    xyz = np.concatenate([rng.uniform(-20, 20, (30_000, 3)), rng.uniform(1.0, 1.04, (5_000, 3))]).astype(np.float32)
+    sensors = [xyzi_cloud(xyz, rng.uniform(0, 10, len(xyz)))]
+    params = MergeParams(leaf=(0.05,) * 3, min_points_per_voxel=2)
+    with capi.CloudMerger(max_points_total=len(xyz), max_sensors=1, flags=capi.FLAG_OCCUPANCY) as cm:
+        flags = []
+        for _ in range(3):
+            g = run_gpu(sensors, params, want_merged=False, cm=cm)
+            st, _, out, rep = oracle.merge_voxelize(sensors, params, stable=True)
+            assert g["res"].n_out == rep.n_out and np.array_equal(g["cells"], rep.cells)
+            assert np.array_equal(g["counts"], rep.counts) and rep.counts.max() >= 5_000
+            assert_centroids_close(g["out"], xyzi_of(out))
+            flags.append(g["res"].path_flags & (BUCKET | REDONE))
+    if sort_path == "classic":
+        assert flags == [0, 0, 0]
+    else:
+        assert flags[0] == REDONE and all(f in (BUCKET, REDONE, 0) for f in flags[1:])
+
+
+def test_async_frames_with_a_box_miss(sort_path):
+    """cm_merge_voxelize_async + cm_wait: the hand-back happens inside cm_wait."""
+    rng = np.random.default_rng(8)
+    a = [xyzi_cloud(rng.uniform(-3, 3, (20_000, 3)), np.ones(20_000))]
+    b = [xyzi_cloud(rng.uniform(-30, 30, (20_000, 3)), np.ones(20_000))]
+    params = MergeParams(leaf=(0.1,) * 3, min_points_per_voxel=0)
+    cp = capi.make_params(params)
+    with capi.CloudMerger(max_points_total=20_000, max_sensors=1, flags=capi.FLAG_OCCUPANCY) as cm:
+        for sensors in (a, b, b):
+            cm.submit_all(sensors)
+            assert cm.merge_voxelize_async(cp) == capi.OK
+            res = cm.wait()
+            cells, counts = cm.cells(res.n_out)
+            st, _, out, rep = oracle.merge_voxelize(sensors, params, stable=True)
+            assert res.n_out == rep.n_out and np.array_equal(cells, rep.cells) and np.array_equal(counts, rep.counts)
