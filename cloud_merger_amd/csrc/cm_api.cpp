@@ -99,6 +99,8 @@ struct cm_ctx {
     float pred_min[3] = {0, 0, 0}, pred_max[3] = {0, 0, 0};
     int v2_variant = 1;                  // local finish geometry: 1 2048-record tiles (2 workgroups/CU), 2 4096 (1/CU, longer bucket tails)
     uint32_t v2_extra_passes = 0;        // buckets overflowed LDS: sort more bits globally
+    uint32_t v2_good_frames = 0;         // bucket-path frames since the last overflow
+    uint32_t v2_retry_after = 256;       // ... after this many, try one global pass fewer again (doubles on failure)
     uint32_t v2_off_frames = 0;          // ... or give the path a rest
     bool last_v2 = false, last_predicted = false;
     cm_params last_params;
@@ -630,7 +632,11 @@ int wait_frame(cm_ctx* c, cm_result* res) {
             const CmFrameState& h0 = *c->h_state;
             if (h0.outside || h0.err == CM_DEV_ERR_BUCKET || h0.err == CM_DEV_ERR_LOOKBACK) {
                 if (h0.outside) c->pred_ok = false;
-                if (h0.err == CM_DEV_ERR_BUCKET && c->v2_extra_passes < CM_MAX_PASSES) ++c->v2_extra_passes;
+                if (h0.err == CM_DEV_ERR_BUCKET) {
+                    if (c->v2_extra_passes < CM_MAX_PASSES) ++c->v2_extra_passes;
+                    if (c->v2_good_frames < 8 && c->v2_retry_after < (1u << 20)) c->v2_retry_after *= 2;   // the retry failed at once
+                    c->v2_good_frames = 0;
+                }
                 if (h0.err == CM_DEV_ERR_LOOKBACK) c->v2_off_frames = 0xFFFFFFFFu;
                 ++c->n_redone;
                 redone = true;
@@ -654,6 +660,10 @@ int wait_frame(cm_ctx* c, cm_result* res) {
                 r.n_sensors = c->n_sensors_used;
                 r.n_in = c->n_in;
             }
+        }
+        if (c->last_v2 && c->v2_extra_passes && ++c->v2_good_frames >= c->v2_retry_after) {
+            --c->v2_extra_passes;                          // the scene may have thinned out: try with less global sorting
+            c->v2_good_frames = 0;
         }
         const CmFrameState& h = *c->h_state;
         if (h.err) {

@@ -611,3 +611,17 @@ def test_async_frames_with_a_box_miss(sort_path):
             cells, counts = cm.cells(res.n_out)
             st, _, out, rep = oracle.merge_voxelize(sensors, params, stable=True)
             assert res.n_out == rep.n_out and np.array_equal(cells, rep.cells) and np.array_equal(counts, rep.counts)
+
+
+@pytest.mark.parametrize("leaf,half,n_pass", [(0.01, (6.345, 6.345, 6.345), 3), (0.5, (4.0, 4.0, 2.0), 1), (0.1, (20.0, 20.0, 4.0), 2)])
+def test_bucket_path_one_to_three_global_passes(leaf, half, n_pass, sort_path):
+    """Index widths of 31, 11 and 25 bits: three, one and two global passes before the local finish."""
+    rng = np.random.default_rng(12)
+    half = np.asarray(half, np.float32)
+    xyz = rng.uniform(-1.2, 1.2, (60_000, 3)).astype(np.float32) * half          # some points outside the box
+    sensors = [xyzi_cloud(xyz[:30_000], rng.uniform(0, 50, 30_000)), xyzi_cloud(xyz[30_000:], rng.uniform(0, 50, 30_000))]
+    params = MergeParams(leaf=(leaf,) * 3, min_points_per_voxel=0, crop_min=tuple(-half), crop_max=tuple(half))
+    g, rep = check_against_oracle(sensors, params, exact_small_runs=True)
+    assert g["res"].bounds_from_crop == 1
+    if sort_path == "auto":
+        assert g["res"].path_flags & BUCKET and g["res"].sort_passes == n_pass
