@@ -509,7 +509,12 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
         if (gm != 0) {
             f.box_key_bits = kb;
             f.box_predicted = gm == 2 ? 1u : 0u;
-            uint32_t g = 1 + (kb > CM2_MAX_LOW_BITS + 8 ? (kb - CM2_MAX_LOW_BITS - 1) / 8 : 0) + c->v2_extra_passes;
+            // Global passes: enough that at most CM2_MAX_LOW_BITS index bits are left to the local finish, and
+            // enough that an average bucket (points / 2^(8 g)) stays well inside its LDS capacity; a frame that
+            // overflows anyway is handed back and v2_extra_passes adds a pass for the frames after it.
+            uint32_t g = 1 + (kb > CM2_MAX_LOW_BITS + 8 ? (kb - CM2_MAX_LOW_BITS - 1) / 8 : 0);
+            while (g < CM_MAX_PASSES && (c->n_in >> (8 * g)) > 256) ++g;
+            g += c->v2_extra_passes;
             if (g > 1 && 8 * (g - 1) >= kb) g = 0;           // nothing left for the local finish to add
             if (g >= 1 && g <= CM_MAX_PASSES) {
                 const uint32_t low = kb > 8 * g ? kb - 8 * g : 0;

@@ -465,7 +465,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 3) void k2_scatter(const CmFrameDev* __r
 #define CM2_FLAG_PREFIX (2ull << 32)
 
 template <int LT, int LCAP, int LBLOCK>
-__global__ __launch_bounds__(LBLOCK) void k2_local(const CmFrameDev* __restrict__ fd,
+__global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const CmFrameDev* __restrict__ fd,
                                                        CmFrameState* __restrict__ st,
                                                        CmFrameState* __restrict__ st_next,
                                                        uint32_t* __restrict__ host_state,
@@ -478,7 +478,6 @@ __global__ __launch_bounds__(LBLOCK) void k2_local(const CmFrameDev* __restrict_
     constexpr int LWAVES = LBLOCK / 64, LITEMS = (LCAP + LBLOCK - 1) / LBLOCK, EXT0 = LBLOCK < 256 ? LBLOCK : 256;
     constexpr int BINS = 1024, HWORDS = BINS / 2;          // two 16-bit counters per LDS word
     static_assert(LT == 4 * LBLOCK && LCAP <= 0xFFFF && HWORDS <= LBLOCK && LWAVES * HWORDS * 2 >= LCAP, "tile geometry");
-    __shared__ float4 sp[LCAP];                        // records of the tile, by slot (never move)
     __shared__ uint32_t sk[LCAP];                      // key of every slot
     __shared__ uint16_t si[LCAP];                      // slots in sorted order
     __shared__ uint32_t whist[LWAVES][HWORDS];         // digit counts per wave; after the sort: head positions
@@ -524,9 +523,9 @@ __global__ __launch_bounds__(LBLOCK) void k2_local(const CmFrameDev* __restrict_
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const uint32_t q = r * LBLOCK + threadIdx.x;
-            if (q < nom) { sp[q] = r4[r]; sk[q] = key_of(b, r4[r]); }
+            if (q < nom) sk[q] = key_of(b, r4[r]);
         }
-        if (has_e) { sp[LT + threadIdx.x] = e4; sk[LT + threadIdx.x] = key_of(b, e4); }
+        if (has_e) sk[LT + threadIdx.x] = key_of(b, e4);
         if (threadIdx.x == 0) { s_keyprev = base > 0 ? key_of(b, pv) : 0u; s_a = 0xFFFFFFFFu; }
     }
     __syncthreads();
@@ -560,7 +559,7 @@ __global__ __launch_bounds__(LBLOCK) void k2_local(const CmFrameDev* __restrict_
                 const float4 r4 = rec[j];
                 const uint32_t k = key_of(b, r4);
                 mm = (k >> L) == h_last;
-                if (mm && pos < LCAP) { sp[pos] = r4; sk[pos] = k; }
+                if (mm && pos < LCAP) sk[pos] = k;
             }
             const uint32_t c = __syncthreads_count(mm);
             ext += c;
@@ -581,14 +580,17 @@ __global__ __launch_bounds__(LBLOCK) void k2_local(const CmFrameDev* __restrict_
         const uint32_t npass = nb ? (nb + 9u) / 10u : 1u;
         const uint32_t width = nb ? (nb + npass - 1u) / npass : 0u;
         const uint32_t dmask = (1u << width) - 1u;
+        // Wave w ranks the contiguous chunk [w * 64 * rounds, (w + 1) * 64 * rounds) of the owned records: all
+        // waves equally busy whatever m is (LITEMS only bounds the capacity).
+        const uint32_t rounds = (m + LBLOCK - 1) / LBLOCK;
         for (uint32_t p = 0; p < npass; ++p) {
             uint32_t dg[LITEMS], rk[LITEMS];
             uint16_t ei[LITEMS];
 #pragma unroll
             for (int r = 0; r < LITEMS; ++r) {
-                const uint32_t e = w * (64 * LITEMS) + r * 64 + lane;
+                const uint32_t e = w * (64 * rounds) + r * 64 + lane;
                 ei[r] = 0; dg[r] = 0;
-                if (e < m) {
+                if (r < rounds && e < m) {
                     ei[r] = (p == 0) ? static_cast<uint16_t>(a + e) : si[e];
                     dg[r] = ((sk[ei[r]] - kbase) >> (p * width)) & dmask;
                 }
@@ -598,9 +600,10 @@ __global__ __launch_bounds__(LBLOCK) void k2_local(const CmFrameDev* __restrict_
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < LITEMS; ++r) {
-                const uint32_t e = w * (64 * LITEMS) + r * 64 + lane;
+                const uint32_t e = w * (64 * rounds) + r * 64 + lane;
                 const uint32_t sh = (dg[r] & 1u) * 16u;
-                rk[r] = (e < m) ? ((atomicAdd(&whist[w][dg[r] >> 1], 1u << sh) >> sh) & 0xFFFFu) : 0u;
+                rk[r] = 0;
+                if (r < rounds && e < m) rk[r] = (atomicAdd(&whist[w][dg[r] >> 1], 1u << sh) >> sh) & 0xFFFFu;
             }
             __syncthreads();
             // thread t < HWORDS: digits 2t and 2t+1 — exclusive prefix over the waves, then over the digits
@@ -622,8 +625,8 @@ __global__ __launch_bounds__(LBLOCK) void k2_local(const CmFrameDev* __restrict_
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < LITEMS; ++r) {
-                const uint32_t e = w * (64 * LITEMS) + r * 64 + lane;
-                if (e < m) {
+                const uint32_t e = w * (64 * rounds) + r * 64 + lane;
+                if (r < rounds && e < m) {
                     const uint32_t pos = dbase[dg[r]] + ((whist[w][dg[r] >> 1] >> ((dg[r] & 1u) * 16u)) & 0xFFFFu) + rk[r];
                     si[pos] = ei[r];
                 }
@@ -635,12 +638,13 @@ __global__ __launch_bounds__(LBLOCK) void k2_local(const CmFrameDev* __restrict_
     // ---- voxels of the tile: a head is a sorted item whose key differs from the one before it.
     // hpos[v] = sorted position of voxel v's first point (the counters' LDS is free now).
     uint32_t heads = 0, nh = 0;
+    const uint32_t per = (m + LBLOCK - 1) / LBLOCK;        // sorted items per thread (<= LITEMS)
     {
-        const uint32_t i0 = threadIdx.x * LITEMS;
+        const uint32_t i0 = threadIdx.x * per;
         uint32_t kp = (i0 > 0 && i0 < m) ? sk[si[i0 - 1]] : 0u;
 #pragma unroll
         for (int j = 0; j < LITEMS; ++j) {
-            if (i0 + j < m) {
+            if (static_cast<uint32_t>(j) < per && i0 + j < m) {
                 const uint32_t k = sk[si[i0 + j]];
                 if (i0 + j == 0 || k != kp) { heads |= 1u << j; ++nh; }
                 kp = k;
@@ -650,7 +654,7 @@ __global__ __launch_bounds__(LBLOCK) void k2_local(const CmFrameDev* __restrict_
     uint32_t n_vox;
     {
         uint32_t v = block_excl_scan_w<LWAVES>(nh, lds, &n_vox);     // its barriers also retire the last reads of whist
-        const uint32_t i0 = threadIdx.x * LITEMS;
+        const uint32_t i0 = threadIdx.x * per;
 #pragma unroll
         for (int j = 0; j < LITEMS; ++j)
             if (heads >> j & 1u) hpos[v++] = static_cast<uint16_t>(i0 + j);
@@ -658,18 +662,19 @@ __global__ __launch_bounds__(LBLOCK) void k2_local(const CmFrameDev* __restrict_
     __syncthreads();
 
     // ---- kept voxels (A.4 step 7: at least min_pts points), published at once for the look-back
-    // Thread t takes voxels [6t, 6t+6): a wave covers 384 consecutive voxels (similar run lengths), and
-    // the kept ones get consecutive output slots from one scan.
+    // Thread t takes voxels [t * pv, (t + 1) * pv): a wave covers 64 * pv consecutive voxels (similar run
+    // lengths), and the kept ones get consecutive output slots from one scan.
     uint32_t vstart[LITEMS], vlen[LITEMS];
     uint32_t nkeep = 0;
+    const uint32_t pv = (n_vox + LBLOCK - 1) / LBLOCK;
     {
-        const uint32_t v0 = threadIdx.x * LITEMS;
+        const uint32_t v0 = threadIdx.x * pv;
         uint32_t hp = (v0 < n_vox) ? hpos[v0] : m;
 #pragma unroll
         for (int j = 0; j < LITEMS; ++j) {
             const uint32_t v = v0 + j;
             vstart[j] = hp; vlen[j] = 0;
-            if (v < n_vox) {
+            if (static_cast<uint32_t>(j) < pv && v < n_vox) {
                 const uint32_t nx = (v + 1 < n_vox) ? hpos[v + 1] : m;
                 vlen[j] = (nx - hp >= min_pts) ? nx - hp : 0u;
                 nkeep += vlen[j] ? 1u : 0u;
@@ -733,9 +738,9 @@ __global__ __launch_bounds__(LBLOCK) void k2_local(const CmFrameDev* __restrict_
     for (int j = 0; j < LITEMS; ++j) {
         acc[j].x = acc[j].y = acc[j].z = acc[j].i = 0.f; acc[j].c = 0;
         if (vlen[j]) {
-            float4 s4 = sp[si[vstart[j]]];
+            float4 s4 = rec[base + si[vstart[j]]];
             for (uint32_t e = 1; e < vlen[j]; ++e) {
-                const float4 r4 = sp[si[vstart[j] + e]];
+                const float4 r4 = rec[base + si[vstart[j] + e]];
                 s4.x = __fadd_rn(s4.x, r4.x); s4.y = __fadd_rn(s4.y, r4.y);
                 s4.z = __fadd_rn(s4.z, r4.z); s4.w = __fadd_rn(s4.w, r4.w);
             }
@@ -796,9 +801,9 @@ void cmk2_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameSt
     const float4* r = reinterpret_cast<const float4*>(rec);
     float4* o = reinterpret_cast<float4*>(out);
     if (variant <= 1)
-        hipLaunchKernelGGL((k2_local<2048, 2816, 512>), dim3(n_padded / 2048), dim3(512), 0, s, fd, st, st_next, host_state,
+        hipLaunchKernelGGL((k2_local<2048, 4096, 512>), dim3(n_padded / 2048), dim3(512), 0, s, fd, st, st_next, host_state,
                            r, tile_state, o, out_key, out_cnt, low_bits);
     else
-        hipLaunchKernelGGL((k2_local<4096, 5632, 1024>), dim3(n_padded / 4096), dim3(1024), 0, s, fd, st, st_next, host_state,
+        hipLaunchKernelGGL((k2_local<4096, 8192, 1024>), dim3(n_padded / 4096), dim3(1024), 0, s, fd, st, st_next, host_state,
                            r, tile_state, o, out_key, out_cnt, low_bits);
 }
