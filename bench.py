@@ -24,7 +24,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
+HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md)
+HBM_COPY_GBS = 6290.0          # measured float4-copy ceiling, same guide (SURVEY.md §8d asks for both)
 
 
 def parse():
@@ -39,7 +40,7 @@ def parse():
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal: every rank uses GPU 0 (needs --backend gloo; not a measurement)")
-    ap.add_argument("--profile-frames", type=int, default=20)
+    ap.add_argument("--profile-frames", type=int, default=50, help="frames timed alone with HIP events (median t_device)")
     ap.add_argument("--outlier-radius", type=float, default=0.0,
                     help="also run pcl::RadiusOutlierRemoval (min 1 neighbour) on the fused cloud before VoxelGrid "
                          "(SURVEY 8f rank 2; off for the headline metric)")
@@ -224,6 +225,7 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "peak_measured_copy": HBM_COPY_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS,
             "scope": f"whole frame pipeline over the timed region ({inflight} independent frames in flight): "
                      "16*N_in + 16*M algorithmic bytes per frame / (elapsed / steps)",
             "algorithmic_bytes_per_frame": b_alg,
