@@ -71,6 +71,10 @@ def check_against_oracle(sensors, params, exact_small_runs=False):
     if exact_small_runs:      # one- and two-point voxels have a single summation order
         small = rep.counts <= 2
         assert same_bits(g["out"][small], xyzi_of(out)[small])
+    if g["res"].path_flags & BUCKET:
+        # The bucket path adds a voxel's points one after the other in stable (sensor, point) order and
+        # divides with correct rounding: the same fp32 operations as the oracle run with stable=True.
+        assert same_bits(g["out"], xyzi_of(out)), "bucket path: centroids must equal the stable-order oracle bit for bit"
     return g, rep
 
 
