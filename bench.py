@@ -287,11 +287,16 @@ def main():
                 times.append(rep.t_total_s)
             st1, _, _, rep1 = oracle.merge_voxelize(sensors, params, threads=1, stable=False, want_merged=False)
             t_cpu = float(np.median(times))
-            # parity gate on the frame that was just timed
+            # parity gate on the frame that was just timed (oracle with a stable sort: PCL leaves the order of
+            # a voxel's points to std::sort; the stable order is the one the device path reproduces)
+            st, _, ref, rep = oracle.merge_voxelize(sensors, params, threads=6, stable=True, want_merged=False)
             ok = (st == oracle.OK and rep.n_out == n_out and np.array_equal(rep.cells, cells_gpu)
                   and np.array_equal(rep.counts, counts_gpu))
-            dx = float(np.abs(np.stack([out_gpu["x"], out_gpu["y"], out_gpu["z"]], 1).astype(np.float64) -
-                              np.stack([ref["x"], ref["y"], ref["z"]], 1).astype(np.float64)).max()) if ok else None
+            g4 = np.stack([out_gpu["x"], out_gpu["y"], out_gpu["z"], out_gpu["intensity"]], 1)
+            r4 = np.stack([ref["x"], ref["y"], ref["z"], ref["intensity"]], 1)
+            dx = float(np.abs(g4[:, :3].astype(np.float64) - r4[:, :3].astype(np.float64)).max()) if ok else None
+            bits = bool(ok and np.array_equal(np.ascontiguousarray(g4, np.float32).view(np.uint32),
+                                               np.ascontiguousarray(r4, np.float32).view(np.uint32)))
             out["cpu_baseline"] = {
                 "value": n_in / t_cpu, "unit": "points/s", "cores": int(rep.threads_used), "kind": "port",
                 "sample": f"{reps} full frames of the same workload ({n_in} points each), median; CPU restatement "
@@ -303,7 +308,7 @@ def main():
                 "host_cpus": os.cpu_count(),
                 "gpu_over_cpu": (args.steps * n_in / elapsed) / (n_in / t_cpu),
             }
-            out["parity"] = {"occupancy_bit_exact": bool(ok), "max_abs_dxyz_m": dx}
+            out["parity"] = {"occupancy_bit_exact": bool(ok), "max_abs_dxyz_m": dx, "centroids_bit_exact": bits}
         print(json.dumps(out))
     for c in cms:
         c.close()
