@@ -97,7 +97,7 @@ static void test_load_config(const char* tmpdir) {
     FILE* f = std::fopen(path.c_str(), "w");
     std::fprintf(f, "# two sensors\nsensor left /left/points /lidar_left required\nsensor right /right/points /lidar_right optional\n"
                     "leaf 0.05\nmin_points_per_voxel 3\ncrop -1 -2 -3 4 5 6\noutlier 0.2 2\nstamp_from_inputs 1\nrate_hz 20\n"
-                    "voxel_topic /voxels\nmax_points_total 123456\n");
+                    "voxel_topic /voxels\nmax_points_total 123456\nmax_stamp_spread_ms 25\n");
     std::fclose(f);
     NodeConfig c;
     std::string err;
@@ -107,6 +107,7 @@ static void test_load_config(const char* tmpdir) {
     CHECK(c.params.crop_min[2] == -3.0f && c.params.crop_max[0] == 4.0f);
     CHECK(c.params.outlier_enable == 1 && c.params.outlier_radius == 0.2f && c.params.outlier_min_neighbors == 2);
     CHECK(c.stamp_from_inputs && c.rate_hz == 20.0 && c.voxel_topic == "/voxels" && c.max_points_total == 123456);
+    CHECK(c.max_stamp_spread_ns == 25000000ull);
     CHECK(c.base_frame == "base_footprint");                      // untouched keys keep the reference's values
     f = std::fopen(path.c_str(), "w");
     std::fprintf(f, "leaf -1\n");
@@ -149,6 +150,21 @@ static void test_node_without_gpu_fails_loudly(bool expect_gpu) {
         CHECK(n2.on_cloud(1, cc) == CM_OK);                                // dropped: b already holds a fresh cloud (:356)
         CHECK(n2.spin_once() == CM_OK);
         CHECK(got_pts == 2 && got_stamp == 2500 && got_frame == "base_footprint");   // stamp of the newest FUSED cloud
+        // approximate time synchronisation: clouds 1 s apart are not fused; the older one is dropped
+        NodeConfig c3 = c2;
+        c3.max_stamp_spread_ns = 50ull * 1000 * 1000;                      // 50 ms
+        CloudMergerNode n3(c3);
+        CHECK(n3.ok());
+        n3.set_transform(0, q, t); n3.set_transform(1, q, t);
+        size_t pts3 = 0; uint64_t stamp3 = 0;
+        n3.set_publisher([&](const std::string&, const PointCloud2& out) { pts3 = out.num_points(); stamp3 = out.header.stamp_ns; });
+        ca.header.stamp_ns = 1000000000ull; cb.header.stamp_ns = 2000000000ull;
+        CHECK(n3.on_cloud(0, ca) == CM_OK && n3.on_cloud(1, cb) == CM_OK);
+        CHECK(n3.spin_once() == CM_NOT_READY && n3.clouds_dropped_for_sync() == 1 && n3.frames_published() == 0);
+        ca.header.stamp_ns = 2010000000ull;                                // sensor a's next cloud, 10 ms after b's
+        CHECK(n3.on_cloud(0, ca) == CM_OK);
+        CHECK(n3.spin_once() == CM_OK && pts3 == 2 && stamp3 == 2010000000ull && n3.frames_published() == 1);
+        CHECK(n3.spin_once() == CM_NOT_READY && n3.clouds_dropped_for_sync() == 1);
     } else {
         CHECK(!node.ok() && !node.error().empty());
         CHECK(node.spin_once() == CM_NO_DEVICE);

@@ -78,6 +78,7 @@ bool load_config(const std::string& path, NodeConfig* cfg, std::string* err) {
         } else if (key == "no_crop") c.params.crop_enable = 0;
         else if (key == "outlier") { ok = static_cast<bool>(is >> c.params.outlier_radius >> c.params.outlier_min_neighbors); c.params.outlier_enable = 1; }
         else if (key == "stamp_from_inputs") { int v; ok = static_cast<bool>(is >> v); c.stamp_from_inputs = v != 0; }
+        else if (key == "max_stamp_spread_ms") { double v; ok = static_cast<bool>(is >> v) && v >= 0; c.max_stamp_spread_ns = static_cast<uint64_t>(v * 1e6); }
         else if (key == "max_points_total") ok = static_cast<bool>(is >> c.max_points_total);
         else if (key == "device") ok = static_cast<bool>(is >> c.device);
         else ok = false;
@@ -89,9 +90,10 @@ bool load_config(const std::string& path, NodeConfig* cfg, std::string* err) {
 }
 
 CloudMergerNode::CloudMergerNode(const NodeConfig& cfg)
-    : cfg_(cfg), have_tf_(cfg.sensors.size()), stamp_ns_(cfg.sensors.size()) {
+    : cfg_(cfg), have_tf_(cfg.sensors.size()), stamp_ns_(cfg.sensors.size()), fresh_(cfg.sensors.size()) {
     for (auto& f : have_tf_) f.store(false);
     for (auto& t : stamp_ns_) t.store(0);
+    for (auto& f : fresh_) f.store(false);
     if (cfg_.sensors.empty() || cfg_.sensors.size() > CM_MAX_SENSORS) {
         error_ = "sensor count must be 1..CM_MAX_SENSORS";
         return;
@@ -145,17 +147,39 @@ int CloudMergerNode::on_cloud(size_t sensor, const PointCloud2& msg) {
     if (!l.ok) { error_ = l.error; return CM_BAD_ARG; }
     const int st = cm_submit_cloud(ctx_, static_cast<uint32_t>(sensor), msg.data.data(),
                                    static_cast<uint32_t>(msg.num_points()), msg.point_step, l.off_x, l.off_y, l.off_z, l.off_i);
-    if (st == CM_OK) stamp_ns_[sensor].store(msg.header.stamp_ns);   // CM_SKIPPED: the slot keeps its older cloud
+    if (st == CM_OK) { stamp_ns_[sensor].store(msg.header.stamp_ns); fresh_[sensor].store(true); }   // CM_SKIPPED: the slot keeps its older cloud
     return st == CM_SKIPPED ? CM_OK : st;
 }
 
 int CloudMergerNode::spin_once(cm_result* res) {
     if (!ctx_) return CM_NO_DEVICE;
+    if (cfg_.max_stamp_spread_ns) {
+        // The set the gate (:134) would fuse: every required sensor's unconsumed cloud. Too far apart in time:
+        // drop the oldest and wait for that sensor's next cloud.
+        bool complete = true;
+        uint64_t lo = ~0ull, hi = 0;
+        size_t oldest = 0;
+        for (size_t s = 0; s < cfg_.sensors.size(); ++s) {
+            if (!cfg_.sensors[s].required) continue;
+            if (!fresh_[s].load()) { complete = false; break; }
+            const uint64_t t = stamp_ns_[s].load();
+            if (t < lo) { lo = t; oldest = s; }
+            hi = std::max(hi, t);
+        }
+        if (complete && hi - lo > cfg_.max_stamp_spread_ns) {
+            cm_clear_sensor(ctx_, static_cast<uint32_t>(oldest));
+            fresh_[oldest].store(false);
+            stamp_ns_[oldest].store(0);
+            dropped_.fetch_add(1);
+            return CM_NOT_READY;
+        }
+    }
     cm_result r{};
     const int st = cm_merge_voxelize(ctx_, &cfg_.params, &r);      // fusePointclouds + voxelgrid
     if (res) *res = r;
     if (st == CM_NOT_READY) return st;                              // :575 — nothing fused this tick
     if (st < 0) { error_ = cm_last_error(ctx_); return st; }
+    for (auto& f : fresh_) f.store(false);                          // flag reset, :151-157
     // publishPointcloud, voxel leg (:215-219): PCL layout, stamp = now, frame = base_footprint.
     PointCloud2 msg = cfg_.publish_pcl_layout ? make_pcl_xyzi_message(r.n_out) : make_xyzi16_message(r.n_out);
     if (st == CM_EMPTY_INPUT) { msg.width = 0; msg.height = 0; msg.row_step = 0; }   // A.4 step 1

@@ -39,6 +39,11 @@ struct NodeConfig {
     // true: the newest stamp among the fused input clouds — what pcl::PointCloud::operator+= leaves in
     // the fused cloud's header and what §8f rank 4 proposes.
     bool stamp_from_inputs = false;
+    // Approximate time synchronisation (the reference fuses whatever arrived first since
+    // the last fuse, however far apart in time). 0: off. Otherwise a frame is fused only when the stamps of the
+    // required sensors' clouds lie within this many nanoseconds of each other; if they do not, the oldest
+    // cloud is dropped and the tick is skipped, so that sensor's next cloud can complete the set.
+    uint64_t max_stamp_spread_ns = 0;
 };
 
 // Loads a node description from a text file (an N-sensor configuration instead
@@ -46,7 +51,7 @@ struct NodeConfig {
 //   sensor <name> <topic> <tf_frame> <required|optional>
 //   base_frame <id> | voxel_topic <topic> | rate_hz <v> | leaf <v> | min_points_per_voxel <n>
 //   crop <x0> <y0> <z0> <x1> <y1> <z1> | outlier <radius> <min_neighbors> | stamp_from_inputs <0|1>
-//   max_points_total <n> | device <n>
+//   max_points_total <n> | device <n> | max_stamp_spread_ms <v>
 // Starts from reference_config() minus its sensors when the file names any. Returns false + *err.
 bool load_config(const std::string& path, NodeConfig* cfg, std::string* err);
 
@@ -93,6 +98,7 @@ public:
     void run(const std::atomic<bool>& stop);
 
     uint64_t frames_published() const { return frames_; }
+    uint64_t clouds_dropped_for_sync() const { return dropped_; }
 
 private:
     NodeConfig cfg_;
@@ -104,6 +110,8 @@ private:
     std::atomic<uint64_t> frames_{0};
     uint32_t seq_ = 0;
     std::vector<std::atomic<uint64_t>> stamp_ns_;   // stamp of the cloud each sensor slot currently holds
+    std::vector<std::atomic<bool>> fresh_;          // slot holds a cloud that no fuse has consumed yet
+    std::atomic<uint64_t> dropped_{0};
 };
 
 }  // namespace cloudmerge
