@@ -580,10 +580,14 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
         const uint32_t npass = nb ? (nb + 9u) / 10u : 1u;
         const uint32_t width = nb ? (nb + npass - 1u) / npass : 0u;
         const uint32_t dmask = (1u << width) - 1u;
+        // (per pass: only the counter words its digit can reach are cleared and scanned)
+
         // Wave w ranks the contiguous chunk [w * 64 * rounds, (w + 1) * 64 * rounds) of the owned records: all
         // waves equally busy whatever m is (LITEMS only bounds the capacity).
         const uint32_t rounds = (m + LBLOCK - 1) / LBLOCK;
         for (uint32_t p = 0; p < npass; ++p) {
+            const uint32_t wp = nb > p * width ? min(width, nb - p * width) : 0u;     // bits this pass really sorts
+            const uint32_t words = wp ? ((1u << wp) + 1u) / 2u : 1u;
             uint32_t dg[LITEMS], rk[LITEMS];
             uint16_t ei[LITEMS];
 #pragma unroll
@@ -596,7 +600,10 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
                 }
             }
 #pragma unroll
-            for (int q = 0; q < LWAVES * HWORDS / LBLOCK; ++q) (&whist[0][0])[q * LBLOCK + threadIdx.x] = 0;
+            for (int q = 0; q < LWAVES * HWORDS / LBLOCK; ++q) {
+                const uint32_t flat = q * LBLOCK + threadIdx.x;       // row = flat / HWORDS, column = flat % HWORDS
+                if ((flat & (HWORDS - 1)) < words) (&whist[0][0])[flat] = 0;
+            }
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < LITEMS; ++r) {
@@ -608,7 +615,7 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
             __syncthreads();
             // thread t < HWORDS: digits 2t and 2t+1 — exclusive prefix over the waves, then over the digits
             uint32_t t0 = 0, t1 = 0;
-            if (threadIdx.x < HWORDS) {
+            if (threadIdx.x < words) {
 #pragma unroll
                 for (int q = 0; q < LWAVES; ++q) {
                     const uint32_t c = whist[q][threadIdx.x];
@@ -618,7 +625,7 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
             }
             uint32_t all;
             const uint32_t db = block_excl_scan_w<LWAVES>(t0 + t1, lds, &all);
-            if (threadIdx.x < HWORDS) {
+            if (threadIdx.x < words) {
                 dbase[2 * threadIdx.x] = static_cast<uint16_t>(db);
                 dbase[2 * threadIdx.x + 1] = static_cast<uint16_t>(db + t0);
             }
