@@ -377,7 +377,7 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
     if (!c->rec_a) HIP_TRY(c, hipMalloc(&c->rec_a, npad * 16));
     if (!c->rec_b) HIP_TRY(c, hipMalloc(&c->rec_b, npad * 16));
     if (!c->dig) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->dig), npad));
-    if (!c->tile_state) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->tile_state), (npad / 1024 + 1) * 8));
+    if (!c->tile_state) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->tile_state), (npad / 1024 + 2) * 8));
     if (!c->records) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->records), static_cast<size_t>(c->cap_tiles) * 32));
     if (!c->frame_uploaded_valid || std::memcmp(&f, &c->frame_uploaded, sizeof f) != 0) {
         prof_mark(c, "k_setup");
@@ -402,7 +402,7 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
     c->frame_mask = nullptr;
     prof_mark(c, "k2_hist0");
     cmk2_hist0(st, c->d_frame, state, c->hist, grp0, grp0_next, c->grp + 2 * gstride, gw, static_cast<uint32_t>(gstride),
-               c->tile_state, f.n_padded / 1024 + 1, c->records, grid_mode, low_bits, n_global, nt);
+               c->tile_state, f.n_padded / 1024 + 2, c->records, grid_mode, low_bits, n_global, nt);
     for (uint32_t pass = 0; pass < n_global; ++pass) {
         uint32_t* grp = pass == 0 ? grp0 : c->grp + 2 * gstride + static_cast<size_t>(pass - 1) * gw;
         if (pass > 0) { prof_mark(c, "k2_hist"); cmk2_hist(st, state, c->dig, c->hist, grp, nt); }
@@ -416,7 +416,8 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
     }
     prof_mark(c, "k2_local");
     cmk2_local(st, c->d_frame, state, state_next, c->h_state_dev, ((n_global - 1) & 1u) ? c->rec_b : c->rec_a,
-               c->tile_state, c->out, c->out_key, c->out_cnt, low_bits, f.n_padded, c->v2_variant);
+               c->tile_state, reinterpret_cast<uint32_t*>(c->tile_state + (f.n_padded / 1024 + 1)), c->out, c->out_key,
+               c->out_cnt, low_bits, f.n_padded, c->v2_variant);
     prof_mark(c, "end");
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_done, st));

@@ -54,5 +54,5 @@ void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, CmFrameState*
                   uint32_t shift, uint32_t next_shift, uint32_t n_tiles, uint32_t n_groups, uint32_t n_padded,
                   const float* records, uint32_t n_records, int fold);
 void cmk2_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next, uint32_t* host_state,
-                const void* rec, unsigned long long* tile_state, void* out, uint32_t* out_key, uint32_t* out_cnt,
-                uint32_t low_bits, uint32_t n_padded, int variant);
+                const void* rec, unsigned long long* tile_state, uint32_t* ticket, void* out, uint32_t* out_key,
+                uint32_t* out_cnt, uint32_t low_bits, uint32_t n_padded, int variant);

@@ -471,6 +471,7 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
                                                        uint32_t* __restrict__ host_state,
                                                        const float4* __restrict__ rec,
                                                        unsigned long long* __restrict__ tile_state,
+                                                       uint32_t* __restrict__ ticket,
                                                        float4* __restrict__ out,
                                                        uint32_t* __restrict__ out_key,
                                                        uint32_t* __restrict__ out_cnt,
@@ -486,22 +487,30 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
     __shared__ uint32_t s_a, s_keyprev, s_off;
     uint16_t* hpos = reinterpret_cast<uint16_t*>(&whist[0][0]);
 
-    const uint32_t tile = blockIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (tile == 0 && st_next && threadIdx.x < sizeof(CmFrameState) / 4)
+    // Which tile this workgroup works on is decided when it starts running, by a ticket: it will wait
+    // (look-back below) only for tiles with smaller tickets, i.e. for workgroups that are already running —
+    // whatever order and placement the hardware dispatches workgroups in (several XCDs, other streams, other
+    // processes on the same GPU). Asked for first, so its round trip overlaps the reads of the frame state.
+    if (threadIdx.x == 0) s_a = atomicAdd(ticket, 1u);
+    if (blockIdx.x == 0 && st_next && threadIdx.x < sizeof(CmFrameState) / 4)
         reinterpret_cast<uint32_t*>(st_next)[threadIdx.x] = 0;
     if (st->status != CM_DEV_OK || st->outside) {
-        if (tile == 0) report_state(host_state, st, st->status, 0u, true);
+        if (blockIdx.x == 0) report_state(host_state, st, st->status, 0u, true);
         return;
     }
     const uint32_t n = st->n_valid;
     if (n == 0) {
-        if (tile == 0) report_state(host_state, st, CM_DEV_EMPTY, 0u, true);
+        if (blockIdx.x == 0) report_state(host_state, st, CM_DEV_EMPTY, 0u, true);
         return;
     }
     const uint32_t n_lt = (n + LT - 1) / LT;
+    const BoxGrid b0 = box_grid_of(fd);
+    __syncthreads();
+    const uint32_t tile = s_a;
+    __syncthreads();
     if (tile >= n_lt) return;
-    const BoxGrid b = box_grid_of(fd);
+    const BoxGrid b = b0;
     const uint32_t L = low_bits;
     const uint32_t min_pts = fd->min_pts > 1 ? fd->min_pts : 1u;
 
@@ -803,14 +812,14 @@ void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, CmFrameState*
                            totals, shift, next_shift, n_groups, n_padded, records, n_records, fold);
 }
 void cmk2_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next, uint32_t* host_state,
-                const void* rec, unsigned long long* tile_state, void* out, uint32_t* out_key, uint32_t* out_cnt,
-                uint32_t low_bits, uint32_t n_padded, int variant) {
+                const void* rec, unsigned long long* tile_state, uint32_t* ticket, void* out, uint32_t* out_key,
+                uint32_t* out_cnt, uint32_t low_bits, uint32_t n_padded, int variant) {
     const float4* r = reinterpret_cast<const float4*>(rec);
     float4* o = reinterpret_cast<float4*>(out);
     if (variant <= 1)
         hipLaunchKernelGGL((k2_local<2048, 4096, 512>), dim3(n_padded / 2048), dim3(512), 0, s, fd, st, st_next, host_state,
-                           r, tile_state, o, out_key, out_cnt, low_bits);
+                           r, tile_state, ticket, o, out_key, out_cnt, low_bits);
     else
         hipLaunchKernelGGL((k2_local<4096, 8192, 1024>), dim3(n_padded / 4096), dim3(1024), 0, s, fd, st, st_next, host_state,
-                           r, tile_state, o, out_key, out_cnt, low_bits);
+                           r, tile_state, ticket, o, out_key, out_cnt, low_bits);
 }
