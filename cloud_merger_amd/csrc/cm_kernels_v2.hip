@@ -488,11 +488,6 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
     uint16_t* hpos = reinterpret_cast<uint16_t*>(&whist[0][0]);
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    // Which tile this workgroup works on is decided when it starts running, by a ticket: it will wait
-    // (look-back below) only for tiles with smaller tickets, i.e. for workgroups that are already running —
-    // whatever order and placement the hardware dispatches workgroups in (several XCDs, other streams, other
-    // processes on the same GPU). Asked for first, so its round trip overlaps the reads of the frame state.
-    if (threadIdx.x == 0) s_a = atomicAdd(ticket, 1u);
     if (blockIdx.x == 0 && st_next && threadIdx.x < sizeof(CmFrameState) / 4)
         reinterpret_cast<uint32_t*>(st_next)[threadIdx.x] = 0;
     if (st->status != CM_DEV_OK || st->outside) {
@@ -505,11 +500,18 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
         return;
     }
     const uint32_t n_lt = (n + LT - 1) / LT;
+    // The grid is sized for the padded frame; only n_lt workgroups are needed (a crop may leave far fewer
+    // records than slots): the others leave without drawing a ticket.
+    if (blockIdx.x >= n_lt) return;
+    // Which tile this workgroup works on is decided when it starts running, by a ticket: it will wait
+    // (look-back below) only for tiles with smaller tickets, i.e. for workgroups that are already running —
+    // whatever order and placement the hardware dispatches workgroups in (several XCDs, other streams, other
+    // processes on the same GPU). The n_lt workgroups that stay draw the tickets 0 .. n_lt-1 between them.
+    if (threadIdx.x == 0) s_a = atomicAdd(ticket, 1u);
     const BoxGrid b0 = box_grid_of(fd);
     __syncthreads();
     const uint32_t tile = s_a;
     __syncthreads();
-    if (tile >= n_lt) return;
     const BoxGrid b = b0;
     const uint32_t L = low_bits;
     const uint32_t min_pts = fd->min_pts > 1 ? fd->min_pts : 1u;
