@@ -30,7 +30,9 @@ SYMBOLS = [
     "cm_result_copy_cells", "cm_merged_copy", "cm_get_stage_times", "cm_status_string",
     "cm_last_error", "cm_version", "cm_host_alloc", "cm_host_free",
     "cm_local_bounds", "cm_merge_partial", "cm_partial_device", "cm_partial_copy", "cm_merge_tables",
+    "cm_set_ground_removal", "cm_ground_copy", "cm_ground_planes",
 ]
+MAX_ZONES = 8
 
 # cm_partial_entry (32 bytes)
 ENTRY_DTYPE = np.dtype([("key", "<u4"), ("count", "<u4"), ("sx", "<f4"), ("sy", "<f4"), ("sz", "<f4"),
@@ -57,6 +59,36 @@ class Result(C.Structure):
                 ("min_p", C.c_float * 3), ("max_p", C.c_float * 3),
                 ("bounds_from_crop", C.c_uint32), ("key_bits", C.c_uint32), ("sort_passes", C.c_uint32),
                 ("path_flags", C.c_uint32), ("device_ms", C.c_float)]
+
+
+class Zone(C.Structure):
+    _fields_ = [("x_min", C.c_float), ("x_length", C.c_float), ("z_max_ground", C.c_float)]
+
+
+class GroundParams(C.Structure):
+    _fields_ = [("max_iterations", C.c_uint32), ("distance_threshold", C.c_float), ("probability", C.c_float),
+                ("optimize_coefficients", C.c_int32), ("z_keep_max", C.c_float), ("outlier_radius", C.c_float),
+                ("outlier_min_neighbors", C.c_uint32), ("_pad", C.c_uint32), ("seed", C.c_uint64),
+                ("n_zones", C.c_uint32 * MAX_SENSORS), ("zones", (Zone * MAX_ZONES) * MAX_SENSORS)]
+
+
+class GroundPlane(C.Structure):
+    _fields_ = [("plane", C.c_float * 4), ("band_points", C.c_uint32), ("inliers", C.c_uint32),
+                ("iterations", C.c_uint32), ("found", C.c_int32)]
+
+
+def make_ground_params(zones_per_sensor, max_iterations=1000, distance_threshold=0.3, probability=0.99,
+                       optimize=True, z_keep_max=3.0, seed=12345):
+    """zones_per_sensor: list (one entry per sensor) of lists of (x_min, x_length, z_max_ground); a negative
+    z_max_ground keeps the slab whole. Defaults: the reference's Parameter.h:35-42."""
+    g = GroundParams()
+    g.max_iterations, g.distance_threshold, g.probability = max_iterations, distance_threshold, probability
+    g.optimize_coefficients, g.z_keep_max, g.seed = int(optimize), z_keep_max, seed
+    for s, zs in enumerate(zones_per_sensor):
+        g.n_zones[s] = len(zs)
+        for k, (x0, ln, zm) in enumerate(zs):
+            g.zones[s][k] = Zone(x0, ln, zm)
+    return g
 
 
 class StageTimes(C.Structure):
@@ -114,6 +146,9 @@ def load():
     L.cm_partial_device.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     L.cm_partial_copy.argtypes = [vp, vp, u64]
     L.cm_merge_tables.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), u32, C.POINTER(Params), C.POINTER(Result)]
+    L.cm_set_ground_removal.argtypes = [vp, C.POINTER(GroundParams)]
+    L.cm_ground_copy.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    L.cm_ground_planes.argtypes = [vp, C.POINTER(GroundPlane), u32]
     L.cm_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
     L.cm_host_free.argtypes = [vp]
     for name in SYMBOLS:
@@ -286,6 +321,22 @@ class CloudMerger:
         return out[: n.value].copy()
 
     # ---- fused cloud across GPUs ----
+    def set_ground_removal(self, gparams):
+        """gparams: GroundParams (make_ground_params) or None to switch the stage off."""
+        self._check(self._lib.cm_set_ground_removal(self._ctx, C.byref(gparams) if gparams is not None else None),
+                    "cm_set_ground_removal")
+
+    def ground(self, capacity):
+        out = np.zeros(int(capacity), dtype=XYZI_DTYPE)
+        n = C.c_uint64()
+        self._check(self._lib.cm_ground_copy(self._ctx, out.ctypes.data, int(capacity), C.byref(n)), "cm_ground_copy")
+        return out[:n.value]
+
+    def ground_planes(self):
+        arr = (GroundPlane * (MAX_SENSORS * MAX_ZONES))()
+        self._check(self._lib.cm_ground_planes(self._ctx, arr, MAX_SENSORS * MAX_ZONES), "cm_ground_planes")
+        return arr
+
     def local_bounds(self, params: MergeParams):
         mn, mx, n = (C.c_float * 3)(), (C.c_float * 3)(), C.c_uint64()
         self._check(self._lib.cm_local_bounds(self._ctx, C.byref(make_params(params)), mn, mx, C.byref(n)),

@@ -89,6 +89,17 @@ struct cm_ctx {
     bool have_result = false;
     bool out_is_merged = false;
 
+    // zone-wise ground removal (cm_kernels_ground.hip)
+    bool ground_on = false;
+    CmGroundDev ground;                  // host copy of the slab table
+    bool ground_uploaded = false;
+    CmGroundDev* d_ground = nullptr;
+    CmFrameState* d_state_g = nullptr;   // state of the slab sort
+    unsigned char* gmask = nullptr;      // ground points of the last frame (padded index space)
+    uint32_t* zone_off = nullptr;
+    CmGroundPlaneDev* d_planes = nullptr;
+    bool frame_had_ground = false;
+
     // bucket path (cm_kernels_v2.hip)
     int path_mode = 0;                   // CM_PATH: 0 auto (bucket path when it applies), 1 classic only, 2 bucket only where it applies
     void *rec_a = nullptr, *rec_b = nullptr;      // 16-byte point records, ping-pong
@@ -205,6 +216,7 @@ void free_all(cm_ctx* c) {
     F(c->keys_a); F(c->keys_b); F(c->vals_a); F(c->vals_b); F(c->hist); F(c->totals);
     F(c->seg_counts); F(c->seg_tile_counts); F(c->seg_groups); F(c->grp); F(c->partials); F(c->out_key); F(c->out_cnt); F(c->merged_total); F(c->out); F(c->merged); F(c->partial); F(c->table_entries); F(c->mask); F(c->sorted_pts); F(c->rows); F(c->d_state_o);
     F(c->rec_a); F(c->rec_b); F(c->dig); F(c->tile_state); F(c->records);
+    F(c->d_ground); F(c->d_state_g); F(c->gmask); F(c->zone_off); F(c->d_planes);
     F(c->d_frame); F(c->d_state[0]); F(c->d_state[1]);
     if (c->h_state) (void)hipHostFree(c->h_state);
     for (auto& s : c->slots) {
@@ -444,6 +456,7 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
     for (int a = 0; a < 3; ++a) inv_leaf[a] = 1.0f / p->leaf[a];
     const bool outl = p->outlier_enable != 0;
     if (outl && mode != 0) return fail(c, CM_BAD_ARG, "outlier removal needs the whole fused cloud on one GPU (not with partial tables)");
+    if (c->ground_on && (outl || mode != 0)) return fail(c, CM_BAD_ARG, "ground removal is not combined with outlier_enable or partial tables");
     if (outl && (!(p->outlier_radius > 0.0f) || !std::isfinite(p->outlier_radius))) return fail(c, CM_BAD_ARG, "outlier_radius must be > 0");
     if (outl) for (int a = 0; a < 3; ++a) inv_cell[a] = 1.0f / (p->outlier_radius * 1.01f);   // candidate grid a little wider than r
     uint32_t key_bits = 0, kb_o = 0;
@@ -489,7 +502,7 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
 
     // Bucket path: centroids of one GPU's whole frame, with a box known before the first point is
     // read — the crop box, or the last frame's bounds plus a margin (verified on the device).
-    bool want_v2 = c->path_mode != 1 && mode == 0 && !outl && c->lds_rank;
+    bool want_v2 = c->path_mode != 1 && mode == 0 && !outl && !c->ground_on && c->lds_rank;
     if (want_v2 && c->v2_off_frames) { --c->v2_off_frames; want_v2 = false; }
     if (want_v2) {
         int gm = grid_mode;
@@ -580,6 +593,37 @@ int launch_classic(cm_ctx* c, const cm_params* p, int mode, int grid_mode, uint3
     };
 
     c->frame_mask = nullptr;
+    c->frame_had_ground = false;
+    if (c->ground_on && mode == 0) {
+        // Zone-wise ground removal first (per sensor, before the fuse): it leaves a keep-mask for the voxel
+        // grid and the fused no-ground cloud, and a ground mask for the fused ground cloud.
+        if (!c->mask) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->mask), c->cap_padded));
+        if (!c->gmask) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->gmask), c->cap_padded));
+        if (!c->sorted_pts) HIP_TRY(c, hipMalloc(&c->sorted_pts, static_cast<size_t>(c->cap_padded) * 16));
+        if (!c->d_ground) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_ground), sizeof(CmGroundDev)));
+        if (!c->d_state_g) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_state_g), sizeof(CmFrameState)));
+        if (!c->zone_off) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->zone_off), (CM_DEV_MAX_SENSORS * CM_DEV_MAX_ZONES + 1) * 4));
+        if (!c->d_planes) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_planes), CM_DEV_MAX_SENSORS * CM_DEV_MAX_ZONES * sizeof(CmGroundPlaneDev)));
+        if (!c->ground_uploaded) { cmkg_setup(st, c->ground, c->d_ground); c->ground_uploaded = true; }
+        HIP_TRY(c, hipMemsetAsync(c->d_state_g, 0, sizeof(CmFrameState), st));
+        HIP_TRY(c, hipMemsetAsync(c->mask, 0, f.n_padded, st));
+        HIP_TRY(c, hipMemsetAsync(c->gmask, 0, f.n_padded, st));
+        uint32_t* grp0 = c->grp + gstride * (c->frame_seq & 1u);
+        uint32_t* grp0_next = c->grp + gstride * ((c->frame_seq & 1u) ^ 1u);
+        ++c->frame_seq;
+        prof_mark(c, "kg_classify");
+        cmkg_classify(st, c->d_frame, c->d_ground, c->d_state_g, c->keys_a, c->hist, grp0, grp0_next, c->grp + 2 * gstride,
+                      gw, static_cast<uint32_t>(gstride), c->mask, nt);
+        if (big) { prof_mark(c, "k_gscan"); cmk_gscan(st, c->d_state_g, grp0, c->totals, 0, n_groups); }
+        prof_mark(c, "k_scatter(slabs)");
+        cmk_scatter(st, c->d_state_g, c->keys_a, c->vals_a, c->keys_b, c->vals_b, c->hist, grp0, big ? c->totals : nullptr, 0, nt,
+                    n_groups, f.n_padded, c->lds_rank);
+        prof_mark(c, "kg_ransac");
+        cmkg_planes(st, c->d_frame, c->d_ground, c->d_state_g, c->keys_b, c->vals_b, c->sorted_pts, c->zone_off, c->d_planes,
+                    c->mask, c->gmask, f.n_padded);
+        c->frame_mask = c->mask;
+        c->frame_had_ground = true;
+    }
     if (outl) {
         // Radius outlier removal first: it decides which points the voxel grid sees at all.
         if (!c->mask) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->mask), c->cap_padded));
@@ -1021,6 +1065,77 @@ int cm_merged_copy(cm_ctx* c, void* host_dst, uint64_t capacity, uint64_t* n_poi
         HIP_TRY(c, hipMemcpyAsync(host_dst, c->merged, static_cast<size_t>(total) * 16, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
+    return CM_OK;
+}
+
+int cm_set_ground_removal(cm_ctx* c, const cm_ground_params* g) {
+    if (!c) return CM_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->merge_mu);
+    if (c->pending) return fail(c, CM_BAD_ARG, "cannot change ground removal with a frame in flight");
+    if (!g) { c->ground_on = false; return CM_OK; }
+    if (g->max_iterations < 1 || g->max_iterations > 100000) return fail(c, CM_BAD_ARG, "max_iterations must be in 1..100000");
+    if (!(g->distance_threshold > 0.0f) || !std::isfinite(g->distance_threshold)) return fail(c, CM_BAD_ARG, "distance_threshold must be > 0");
+    if (!(g->probability > 0.0f && g->probability < 1.0f)) return fail(c, CM_BAD_ARG, "probability must be in (0, 1)");
+    if (g->outlier_radius != 0.0f) return fail(c, CM_BAD_ARG, "per-band outlier removal is not available in this version (outlier_radius must be 0)");
+    CmGroundDev d;
+    std::memset(&d, 0, sizeof d);
+    for (uint32_t s = 0; s < CM_MAX_SENSORS; ++s) {
+        if (g->n_zones[s] > CM_MAX_ZONES) return fail(c, CM_BAD_ARG, "more than CM_MAX_ZONES zones for a sensor");
+        d.n_zones[s] = g->n_zones[s];
+        for (uint32_t z = 0; z < g->n_zones[s]; ++z) {
+            const cm_zone& zn = g->zones[s][z];
+            if (!std::isfinite(zn.x_min) || !(zn.x_length >= 0.0f) || !std::isfinite(zn.x_length) || !std::isfinite(zn.z_max_ground))
+                return fail(c, CM_BAD_ARG, "zone limits must be finite, x_length >= 0");
+            d.x0[s][z] = zn.x_min;
+            d.x1[s][z] = zn.x_min + zn.x_length;                          // setFilterLimits(deviation, deviation + length), :57
+            d.zmax[s][z] = zn.z_max_ground;
+            d.zlo[s][z] = static_cast<float>(static_cast<double>(zn.z_max_ground) + 0.01);   // z_max_ground + 0.01, :91
+        }
+    }
+    d.z_keep_max = g->z_keep_max;
+    d.threshold = g->distance_threshold;
+    d.probability = g->probability;
+    d.max_iterations = g->max_iterations;
+    d.optimize = g->optimize_coefficients ? 1u : 0u;
+    d.seed = g->seed;
+    c->ground = d;
+    c->ground_uploaded = false;
+    c->ground_on = true;
+    return CM_OK;
+}
+
+int cm_ground_copy(cm_ctx* c, void* host_dst, uint64_t capacity, uint64_t* n_points) {
+    if (!c || !n_points) return CM_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->merge_mu);
+    if (!c->have_result) return fail(c, CM_BAD_ARG, "no result");
+    *n_points = 0;
+    if (!c->frame_had_ground) return fail(c, CM_BAD_ARG, "the last frame ran without ground removal");
+    if (c->frame.n_padded == 0) return CM_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->merged) HIP_TRY(c, hipMalloc(&c->merged, static_cast<size_t>(c->cap_padded) * 16));
+    uint32_t* counts = c->seg_counts + c->cap_seg_tiles;
+    cmk_merged(c->stream, c->d_frame, counts, c->merged_total, c->merged, c->frame.n_tiles, c->gmask);
+    uint32_t total = 0;
+    HIP_TRY(c, hipMemcpyAsync(&total, c->merged_total, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *n_points = total;
+    if (total > capacity) return fail(c, CM_CAPACITY, "destination too small");
+    if (total && host_dst) {
+        HIP_TRY(c, hipMemcpyAsync(host_dst, c->merged, static_cast<size_t>(total) * 16, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return CM_OK;
+}
+
+int cm_ground_planes(cm_ctx* c, cm_ground_plane* planes, uint32_t capacity) {
+    if (!c || !planes) return CM_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->merge_mu);
+    if (!c->have_result || !c->frame_had_ground) return fail(c, CM_BAD_ARG, "the last frame ran without ground removal");
+    static_assert(sizeof(cm_ground_plane) == sizeof(CmGroundPlaneDev), "plane record layout");
+    const uint32_t n = std::min<uint32_t>(capacity, CM_DEV_MAX_SENSORS * CM_DEV_MAX_ZONES);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(planes, c->d_planes, static_cast<size_t>(n) * sizeof(cm_ground_plane), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return CM_OK;
 }
 

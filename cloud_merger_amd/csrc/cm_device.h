@@ -77,6 +77,29 @@ struct CmFrameDev {
     uint32_t box_predicted;   // 1: the box is a prediction (check every point against it)
 };
 
+// Zone-wise ground removal (cm_kernels_ground.hip): per sensor up to 8 x-slabs, each with a z band.
+#define CM_DEV_MAX_ZONES 8
+#define CM_GROUND_BATCH 32        // RANSAC hypotheses scored per round (PCL's loop usually stops within the first)
+#define CM_GROUND_SPARE 24        // hypotheses beyond max_iterations, for collinear samples that are skipped
+struct CmGroundDev {
+    uint32_t n_zones[CM_DEV_MAX_SENSORS];
+    float x0[CM_DEV_MAX_SENSORS][CM_DEV_MAX_ZONES], x1[CM_DEV_MAX_SENSORS][CM_DEV_MAX_ZONES];
+    float zmax[CM_DEV_MAX_SENSORS][CM_DEV_MAX_ZONES];      // < 0: keep the slab whole
+    float zlo[CM_DEV_MAX_SENSORS][CM_DEV_MAX_ZONES];       // float(double(zmax) + 0.01): where the part above the band starts
+    float z_keep_max;
+    float threshold;
+    float probability;
+    uint32_t max_iterations;
+    uint32_t optimize;
+    uint32_t _pad;
+    unsigned long long seed;
+};
+struct CmGroundPlaneDev {                 // == cm_ground_plane
+    float plane[4];
+    uint32_t band_points, inliers, iterations;
+    int32_t found;
+};
+
 // Per-frame device state, zeroed before the first kernel of a frame.
 struct CmFrameState {
     uint32_t outside;         // bucket path: a point fell outside the predicted box (frame must be redone)

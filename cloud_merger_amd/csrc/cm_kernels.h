@@ -56,3 +56,13 @@ void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, CmFrameState*
 void cmk2_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next, uint32_t* host_state,
                 const void* rec, unsigned long long* tile_state, uint32_t* ticket, void* out, uint32_t* out_key,
                 uint32_t* out_cnt, uint32_t low_bits, uint32_t n_padded, int variant);
+
+// ---- zone-wise ground removal (cm_kernels_ground.hip) ------------------------------------------
+void cmkg_setup(hipStream_t s, const CmGroundDev& g, CmGroundDev* d_ground);
+void cmkg_classify(hipStream_t s, const CmFrameDev* fd, const CmGroundDev* gd, CmFrameState* st, uint32_t* keys,
+                   uint32_t* hist, uint32_t* grp_acc, uint32_t* grp_clear_a, uint32_t* grp_clear_b,
+                   uint32_t n_group_words, uint32_t n_clear_a_words, unsigned char* keep_mask, uint32_t n_tiles);
+// slab offsets + band points in slab order, then one RANSAC workgroup per slab -> keep / ground masks
+void cmkg_planes(hipStream_t s, const CmFrameDev* fd, const CmGroundDev* gd, const CmFrameState* st,
+                 const uint32_t* keys_sorted, const uint32_t* vals_sorted, void* band_pts, uint32_t* zone_off,
+                 CmGroundPlaneDev* planes, unsigned char* keep_mask, unsigned char* ground_mask, uint32_t n_padded);

@@ -200,6 +200,50 @@ CM_API int cm_partial_copy(cm_ctx* ctx, cm_partial_entry* dst, uint64_t capacity
 CM_API int cm_merge_tables(cm_ctx* ctx, const void* const* dev_tables, const uint64_t* n_entries,
                            uint32_t n_tables, const cm_params* p, cm_result* res);
 
+/* ---- zone-wise ground removal before the fuse -------------------------------
+ * What the live node does to every sensor's cloud between getROI and the fuse: proceedFront / proceedRear
+ * (pc_preprocessing_main.cpp:228-312), the top-middle and Livox callbacks (:436-497) — the cropped cloud is
+ * cut into x-slabs (getCloudPart :49-59), and in each slab removeGround (:71-122) takes the points of a z band,
+ * fits one plane to them (RANSAC, Parameter.h:38-42) and calls its inliers ground; the rest of the band and the
+ * part above it (up to z_keep_max) are "no ground". With this enabled the voxel grid (and cm_merged_copy) sees
+ * the fused no-ground cloud (:137-142) and cm_ground_copy returns the fused ground cloud (:144-149).
+ * Differences from the reference, all documented in DESIGN.md §10: RANSAC samples come from a counter-based
+ * generator, not boost::mt19937 (planes agree statistically, not draw for draw); a point on the border of two
+ * slabs goes to the first one only (the reference's closed intervals put it in both); points keep sensor order
+ * (the reference concatenates slab by slab); the radius outlier filter that removeGround applies to the band's
+ * non-ground points (:119) is applied when outlier_radius > 0, among the points of the same slab. */
+#define CM_MAX_ZONES 8
+typedef struct cm_zone {
+    float x_min, x_length;         /* getCloudPart(cloud, part, length, deviation): x in [x_min, x_min + x_length] */
+    float z_max_ground;            /* removeGround(.., -z, z, ..): band z in [-z, z]; negative: no ground removal,
+                                      the slab is kept whole (top-middle's rear part, :440-441) */
+} cm_zone;
+typedef struct cm_ground_params {
+    uint32_t max_iterations;       /* Parameter.h:38 (1000) */
+    float distance_threshold;      /* :40 (0.3 m) */
+    float probability;             /* :41 (0.99) */
+    int32_t optimize_coefficients; /* :95 (true) */
+    float z_keep_max;              /* roi_z_max (:35): the part above a band reaches from z_max_ground + 0.01 up to here (:91) */
+    float outlier_radius;          /* > 0: RadiusOutlierRemoval on every band's non-ground points (:119, Parameter.h:23) */
+    uint32_t outlier_min_neighbors;/* Parameter.h:24 */
+    uint32_t _pad;
+    uint64_t seed;                 /* of the sample generator */
+    uint32_t n_zones[CM_MAX_SENSORS];
+    cm_zone zones[CM_MAX_SENSORS][CM_MAX_ZONES];   /* in the order the reference processes them */
+} cm_ground_params;
+typedef struct cm_ground_plane {
+    float plane[4];                /* a x + b y + c z + d = 0 */
+    uint32_t band_points, inliers, iterations;
+    int32_t found;
+} cm_ground_plane;
+/* NULL switches the stage off. Takes effect with the next cm_merge_voxelize; not combined with
+ * cm_params.outlier_enable or cm_merge_partial. */
+CM_API int cm_set_ground_removal(cm_ctx* ctx, const cm_ground_params* g);
+/* Fused ground cloud of the last frame, 16-byte x,y,z,intensity records in (sensor, point) order. */
+CM_API int cm_ground_copy(cm_ctx* ctx, void* host_dst, uint64_t capacity_points, uint64_t* n_points);
+/* Planes of the last frame, indexed [sensor * CM_MAX_ZONES + zone]; capacity in entries. */
+CM_API int cm_ground_planes(cm_ctx* ctx, cm_ground_plane* planes, uint32_t capacity);
+
 /* ---- host memory helpers (pinned staging for PointCloud2 payloads) --------------------------- */
 CM_API int cm_host_alloc(void** ptr, size_t bytes);
 CM_API int cm_host_free(void* ptr);

@@ -362,3 +362,166 @@ int orc_merge_voxelize(const orc_sensor* sensors, int n_sensors, const orc_param
 }
 
 }  // extern "C"
+
+// ---- ground plane of one zone (header: orc_ransac_plane) -----------------------------------------
+namespace {
+
+inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+inline uint64_t mulhi64(uint64_t a, uint64_t b) { return static_cast<uint64_t>((static_cast<unsigned __int128>(a) * b) >> 64); }
+
+// three distinct indices in [0, n), n >= 3
+inline void sample3(uint64_t seed, uint32_t zone_key, uint32_t j, uint64_t n, uint32_t idx[3]) {
+    const uint64_t base = seed ^ (static_cast<uint64_t>(zone_key) << 40) ^ (static_cast<uint64_t>(j) << 2);
+    const uint64_t i0 = mulhi64(splitmix64(base + 0), n);
+    uint64_t i1 = mulhi64(splitmix64(base + 1), n - 1);
+    if (i1 >= i0) ++i1;
+    uint64_t i2 = mulhi64(splitmix64(base + 2), n - 2);
+    const uint64_t lo = i0 < i1 ? i0 : i1, hi = i0 < i1 ? i1 : i0;
+    if (i2 >= lo) ++i2;
+    if (i2 >= hi) ++i2;
+    idx[0] = static_cast<uint32_t>(i0); idx[1] = static_cast<uint32_t>(i1); idx[2] = static_cast<uint32_t>(i2);
+}
+
+// SampleConsensusModelPlane::computeModelCoefficients, fp32
+inline bool plane_from_3(const orc_point& p0, const orc_point& p1, const orc_point& p2, float pl[4]) {
+    const float ax = p1.x - p0.x, ay = p1.y - p0.y, az = p1.z - p0.z;
+    const float bx = p2.x - p0.x, by = p2.y - p0.y, bz = p2.z - p0.z;
+    const float r0 = ax / bx, r1 = ay / by, r2 = az / bz;          // collinear: all three ratios equal
+    if (r0 == r1 && r2 == r1) return false;
+    float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+    const float len = std::sqrt((nx * nx + ny * ny) + nz * nz);
+    if (!(len > 0.0f)) return false;
+    nx = nx / len; ny = ny / len; nz = nz / len;
+    pl[0] = nx; pl[1] = ny; pl[2] = nz;
+    pl[3] = -1.0f * ((nx * p0.x + ny * p0.y) + nz * p0.z);
+    return std::isfinite(pl[0]) && std::isfinite(pl[1]) && std::isfinite(pl[2]) && std::isfinite(pl[3]);
+}
+inline bool plane_inlier(const float pl[4], const orc_point& p, float thr) {
+    return std::fabs(((pl[0] * p.x + pl[1] * p.y) + pl[2] * p.z) + pl[3]) < thr;
+}
+
+// Symmetric 3x3 eigen-decomposition, cyclic Jacobi, 12 sweeps, fp64; a: xx xy xz yy yz zz. v: columns.
+inline void jacobi3(double a[3][3], double v[3][3]) {
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) v[i][j] = (i == j) ? 1.0 : 0.0;
+    static const int P[3] = {0, 0, 1}, Q[3] = {1, 2, 2};
+    for (int sweep = 0; sweep < 12; ++sweep)
+        for (int r = 0; r < 3; ++r) {
+            const int p = P[r], q = Q[r];
+            const double apq = a[p][q];
+            if (std::fabs(apq) < 1e-300) continue;
+            const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+            const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+            const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+            for (int k = 0; k < 3; ++k) {                 // columns p, q of a
+                const double akp = a[k][p], akq = a[k][q];
+                a[k][p] = c * akp - s * akq;
+                a[k][q] = s * akp + c * akq;
+            }
+            for (int k = 0; k < 3; ++k) {                 // rows p, q of a
+                const double apk = a[p][k], aqk = a[q][k];
+                a[p][k] = c * apk - s * aqk;
+                a[q][k] = s * apk + c * aqk;
+            }
+            for (int k = 0; k < 3; ++k) {
+                const double vkp = v[k][p], vkq = v[k][q];
+                v[k][p] = c * vkp - s * vkq;
+                v[k][q] = s * vkp + c * vkq;
+            }
+        }
+}
+
+}  // namespace
+
+extern "C" void orc_ransac_plane(const orc_point* pts, size_t n, uint32_t max_iterations, float threshold, float probability,
+                                 int optimize, uint64_t seed, uint32_t zone_key, orc_plane_result* res,
+                                 uint8_t* inlier_mask) {
+    std::memset(res, 0, sizeof *res);
+    if (inlier_mask) std::memset(inlier_mask, 0, n);
+    if (n < 3) return;
+    const uint32_t J = max_iterations + 24;
+    // PCL's loop over the hypothesis sequence
+    uint32_t iterations = 0, skipped = 0;
+    long long best = -1;
+    uint32_t best_j = 0;
+    float best_pl[4] = {0, 0, 0, 0};
+    double pno = 1.0, pw = 1.0;
+    const double stop = 1.0 - static_cast<double>(probability);
+    for (;;) {
+        const uint32_t j = iterations + skipped;
+        if (j >= J) break;
+        uint32_t idx[3];
+        sample3(seed, zone_key, j, n, idx);
+        float pl[4];
+        if (!plane_from_3(pts[idx[0]], pts[idx[1]], pts[idx[2]], pl)) { ++skipped; continue; }
+        long long c = 0;
+        for (size_t i = 0; i < n; ++i) c += plane_inlier(pl, pts[i], threshold) ? 1 : 0;
+        bool updated = false;
+        if (c > best) {
+            best = c; best_j = j; std::memcpy(best_pl, pl, sizeof pl);
+            const double w = static_cast<double>(c) / static_cast<double>(n);
+            pno = 1.0 - (w * w) * w;
+            if (pno < 2.220446049250313e-16) pno = 2.220446049250313e-16;
+            if (pno > 1.0 - 2.220446049250313e-16) pno = 1.0 - 2.220446049250313e-16;
+            updated = true;
+        }
+        ++iterations;
+        if (updated) { pw = 1.0; for (uint32_t t = 0; t < iterations; ++t) pw *= pno; }
+        else pw *= pno;
+        if (iterations > max_iterations) break;
+        if (!(pw > stop)) break;
+    }
+    res->iterations = iterations;
+    if (best < 0) return;
+    res->found = 1;
+    res->best_hypothesis = best_j;
+    float pl[4];
+    std::memcpy(pl, best_pl, sizeof pl);
+    if (optimize && best > 3) {
+        double part[256][10];
+        std::memset(part, 0, sizeof part);
+        for (size_t i = 0; i < n; ++i) {
+            if (!plane_inlier(pl, pts[i], threshold)) continue;
+            double* a = part[i & 255];
+            const double x = pts[i].x, y = pts[i].y, z = pts[i].z;
+            a[0] += x; a[1] += y; a[2] += z;
+            a[3] += x * x; a[4] += x * y; a[5] += x * z; a[6] += y * y; a[7] += y * z; a[8] += z * z;
+            a[9] += 1.0;
+        }
+        for (int stride = 128; stride > 0; stride >>= 1)
+            for (int t = 0; t < stride; ++t)
+                for (int k = 0; k < 10; ++k) part[t][k] += part[t + stride][k];
+        const double* S = part[0];
+        const double cnt = S[9];
+        const double mx = S[0] / cnt, my = S[1] / cnt, mz = S[2] / cnt;
+        double a[3][3], v[3][3];
+        a[0][0] = S[3] / cnt - mx * mx; a[0][1] = S[4] / cnt - mx * my; a[0][2] = S[5] / cnt - mx * mz;
+        a[1][1] = S[6] / cnt - my * my; a[1][2] = S[7] / cnt - my * mz; a[2][2] = S[8] / cnt - mz * mz;
+        a[1][0] = a[0][1]; a[2][0] = a[0][2]; a[2][1] = a[1][2];
+        jacobi3(a, v);
+        int m = 0;
+        if (a[1][1] < a[m][m]) m = 1;
+        if (a[2][2] < a[m][m]) m = 2;
+        double nx = v[0][m], ny = v[1][m], nz = v[2][m];
+        const double len = std::sqrt((nx * nx + ny * ny) + nz * nz);
+        nx = nx / len; ny = ny / len; nz = nz / len;
+        const double d = -1.0 * ((nx * mx + ny * my) + nz * mz);
+        if (std::isfinite(nx) && std::isfinite(ny) && std::isfinite(nz) && std::isfinite(d)) {
+            pl[0] = static_cast<float>(nx); pl[1] = static_cast<float>(ny); pl[2] = static_cast<float>(nz);
+            pl[3] = static_cast<float>(d);
+        }
+    }
+    std::memcpy(res->plane, pl, sizeof pl);
+    uint32_t ni = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const bool in = plane_inlier(pl, pts[i], threshold);
+        if (inlier_mask) inlier_mask[i] = in ? 1 : 0;
+        ni += in ? 1u : 0u;
+    }
+    res->n_inliers = ni;
+}

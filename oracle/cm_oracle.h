@@ -114,6 +114,36 @@ int orc_voxelgrid(const orc_point* in, size_t n, const float leaf[3], uint32_t m
 size_t orc_radius_outlier_removal(const orc_point* in, size_t n, float radius, uint32_t min_neighbors,
                                   orc_point* out, uint8_t* keep_mask /* optional, n */);
 
+/* Ground plane of one zone, as removeGround finds it (pc_preprocessing_main.cpp:93-104): pcl::SACSegmentation
+ * with SACMODEL_PLANE, SAC_RANSAC, setMaxIterations, setDistanceThreshold, setProbability,
+ * setOptimizeCoefficients(true); setAxis / setEpsAngle are set there but SACMODEL_PLANE ignores them.
+ * PCL 1.8.1's RandomSampleConsensus::computeModel and SampleConsensusModelPlane, recalled,
+ * restated with these choices where PCL's behaviour depends on things that cannot be reproduced here:
+ *   - samples: hypothesis j of a zone takes three distinct points chosen by splitmix64(seed, zone_key, j)
+ *     (PCL draws them from boost::mt19937 seeded 12345 through a running shuffle: same distribution,
+ *     another sequence) — results agree with PCL's statistically, not draw for draw;
+ *   - PCL's loop is kept: a hypothesis replaces the best one only with strictly more inliers, a collinear
+ *     sample is skipped without counting as an iteration, and the loop ends once
+ *     (1 - w^3)^iterations <= 1 - probability for the best inlier ratio w (PCL: iterations >= log(1-p)/log(1-w^3)),
+ *     or after max_iterations; the power is built by repeated multiplication so that it is the same
+ *     number on every machine;
+ *   - plane of a sample and point-to-plane distance in fp32, PCL's operation order; inlier: |d| < threshold;
+ *   - optimizeModelCoefficients (more than 3 inliers): mean and covariance of the inliers, plane normal =
+ *     eigenvector of the smallest eigenvalue, d = -n . mean; sums in fp64 in a fixed blocked order (element i
+ *     goes to partial i mod 256, the partials are added pairwise: 128, 64, ... 1) and a fixed-sweep Jacobi
+ *     iteration instead of PCL's fp32 running sums and closed-form eigen33, then the inliers are selected again.
+ * found = 0 (fewer than 3 points or no valid sample): no plane, no inliers, like PCL's "could not estimate". */
+typedef struct orc_plane_result {
+    float plane[4];          /* a, b, c, d with a*x + b*y + c*z + d = 0, |(a,b,c)| = 1 */
+    uint32_t n_inliers;
+    uint32_t best_hypothesis;
+    uint32_t iterations;     /* hypotheses PCL's loop looked at */
+    int32_t found;
+} orc_plane_result;
+void orc_ransac_plane(const orc_point* pts, size_t n, uint32_t max_iterations, float threshold, float probability,
+                      int optimize, uint64_t seed, uint32_t zone_key, orc_plane_result* res,
+                      uint8_t* inlier_mask /* n */);
+
 /* Absolute voxel cell of each point: floor(fl32(p * inv_leaf)) per axis (A.4 step 5). */
 void orc_voxel_cells(const orc_point* in, size_t n, const float leaf[3], int32_t* ijk /* 3n */);
 

@@ -35,6 +35,11 @@ class _Params(C.Structure):
                 ("outlier_enable", C.c_int32), ("outlier_radius", C.c_float), ("outlier_min_neighbors", C.c_uint32)]
 
 
+class PlaneResult(C.Structure):
+    _fields_ = [("plane", C.c_float * 4), ("n_inliers", C.c_uint32), ("best_hypothesis", C.c_uint32),
+                ("iterations", C.c_uint32), ("found", C.c_int32)]
+
+
 class Report(C.Structure):
     _fields_ = [("status", C.c_int32), ("threads_used", C.c_int32),
                 ("n_in", C.c_uint64), ("n_merged", C.c_uint64), ("n_out", C.c_uint64),
@@ -71,6 +76,9 @@ def lib():
         L.orc_crop.restype = C.c_size_t
         L.orc_radius_outlier_removal.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_radius_outlier_removal.restype = C.c_size_t
+        L.orc_ransac_plane.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_uint64,
+                                       C.c_uint32, C.POINTER(PlaneResult), C.c_void_p]
+        L.orc_ransac_plane.restype = None
         L.orc_voxel_cells.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.c_void_p]
         L.orc_voxel_cells.restype = None
         L.orc_voxelgrid.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.c_uint32, C.c_int,
@@ -128,6 +136,49 @@ def radius_outlier_removal(points, radius, min_neighbors=1):
     k = lib().orc_radius_outlier_removal(points.ctypes.data, len(points), float(radius), int(min_neighbors),
                                          out.ctypes.data, mask.ctypes.data)
     return out[:k].copy(), mask.astype(bool)
+
+
+def ransac_plane(points, max_iterations=1000, threshold=0.3, probability=0.99, optimize=True, seed=12345, zone_key=0):
+    """Ground plane of one slab's band points (orc_ransac_plane). Returns (PlaneResult, inlier mask)."""
+    points = np.ascontiguousarray(points, dtype=POINT_DTYPE)
+    res = PlaneResult()
+    mask = np.zeros(len(points), dtype=np.uint8)
+    lib().orc_ransac_plane(points.ctypes.data, len(points), int(max_iterations), float(threshold), float(probability),
+                           int(optimize), int(seed), int(zone_key), C.byref(res), mask.ctypes.data)
+    return res, mask.astype(bool)
+
+
+def ground_split(points, zones, sensor, gp):
+    """The per-sensor stage of the live node for one transformed + cropped cloud (proceedFront / proceedRear
+    and the top / Livox callbacks, pc_preprocessing_main.cpp:228-312, :436-497), composed from the pieces above:
+    for every slab (x_min, x_length, z_max_ground) in order — a point on a border goes to the first slab only —
+    band / above-band split (removeGround :81-91), plane on the band, inliers = ground. gp: dict with
+    max_iterations, threshold, probability, optimize, z_keep_max, seed. Returns (keep mask, ground mask, planes)
+    over `points` (no-ground = points[keep], ground = points[ground])."""
+    x, z = points["x"], points["z"]
+    taken = np.zeros(len(points), dtype=bool)
+    keep = np.zeros(len(points), dtype=bool)
+    ground = np.zeros(len(points), dtype=bool)
+    planes = []
+    for k, (x0, ln, zm) in enumerate(zones):
+        x0 = np.float32(x0); x1 = np.float32(x0 + np.float32(ln)); zm = np.float32(zm)
+        inz = ~taken & ~((x < x0) | (x > x1))
+        taken |= inz
+        if zm < 0:
+            keep |= inz
+            planes.append(None)
+            continue
+        band = inz & ~((z < -zm) | (z > zm))
+        zlo = np.float32(np.float64(zm) + 0.01)
+        above = inz & ~band & ~((z < zlo) | (z > np.float32(gp["z_keep_max"])))
+        keep |= above
+        idx = np.nonzero(band)[0]
+        res, inl = ransac_plane(points[idx], gp["max_iterations"], gp["threshold"], gp["probability"], gp["optimize"],
+                                gp["seed"], sensor * 8 + k)
+        ground[idx[inl]] = True
+        keep[idx[~inl]] = True
+        planes.append(res)
+    return keep, ground, planes
 
 
 def voxel_cells(points, leaf):

@@ -1,0 +1,170 @@
+"""Zone-wise ground removal before the fuse: the HIP stage (through the C-ABI) against
+the oracle's restatement of removeGround's RANSAC plane (oracle.ground_split / orc_ransac_plane), same sample
+generator on both sides. Plane coefficients within 1e-6; no-ground and ground clouds bit-exact in content and
+order; the voxel grid of the no-ground cloud with the usual bars."""
+import numpy as np
+import pytest
+
+from cloud_merger_amd import capi, synth
+from cloud_merger_amd.types import MergeParams, xyzi_cloud
+from oracle import oracle
+from tests.util import assert_centroids_close, same_bits, xyzi_of
+
+pytestmark = pytest.mark.gpu
+
+ROI = dict(crop_min=(-15.0, -5.0, -0.5), crop_max=(60.0, 5.0, 3.0))
+# proceedFront's five slabs (Parameter.h:45-55): front, mid2, mid, vehicle, rear — (x_min, x_length, z_max_ground)
+FRONT = [(30.0, 30.0, 2.5), (19.0, 11.0, 2.0), (4.0, 15.0, 1.5), (-4.0, 8.0, 0.3), (-15.0, 11.0, 0.5)]
+GP = dict(max_iterations=1000, threshold=0.3, probability=0.99, optimize=True, z_keep_max=3.0, seed=12345)
+
+
+def scene(rng, n, tilt=0.01, ground_sigma=0.03, obj_frac=0.25):
+    """Tilted noisy ground + boxes above it, vehicle frame."""
+    ng = int(n * (1 - obj_frac))
+    gx, gy = rng.uniform(-15, 60, ng), rng.uniform(-5, 5, ng)
+    g = np.stack([gx, gy, -0.05 + tilt * gx + 0.02 * gy + ground_sigma * rng.standard_normal(ng)], 1)
+    no = n - ng
+    o = np.stack([rng.uniform(-15, 60, no), rng.uniform(-5, 5, no), rng.uniform(0.6, 2.9, no)], 1)
+    xyz = np.concatenate([g, o]).astype(np.float32)
+    return xyz[rng.permutation(n)]
+
+
+def expected(sensors, zones, params, gp):
+    no_ground, ground, planes = [], [], []
+    for s, c in enumerate(sensors):
+        pts = oracle.make_points(np.stack([c.data["x"], c.data["y"], c.data["z"]], 1), c.data["intensity"])
+        tp = oracle.transform(pts, oracle.quat_to_matrix(c.q_xyzw, c.t_xyz))
+        cp = oracle.crop(tp, params.crop_min, params.crop_max) if params.crop_min is not None else tp
+        keep, gr, pl = oracle.ground_split(cp, zones[s], s, gp)
+        no_ground.append(cp[keep]); ground.append(cp[gr]); planes.append(pl)
+    return np.concatenate(no_ground), np.concatenate(ground), planes
+
+
+def run(sensors, zones, params, gp, cm=None):
+    n_total = sum(c.n for c in sensors)
+    own = cm is None
+    if own:
+        cm = capi.CloudMerger(max_points_total=n_total, max_sensors=len(sensors), flags=capi.FLAG_OCCUPANCY)
+    try:
+        cm.set_ground_removal(capi.make_ground_params(zones, gp["max_iterations"], gp["threshold"], gp["probability"],
+                                                      gp["optimize"], gp["z_keep_max"], gp["seed"]))
+        cm.submit_all(sensors)
+        res = cm.merge_voxelize(params)
+        out = cm.result(res.n_out)
+        cells, counts = cm.cells(res.n_out) if res.status == capi.OK else (None, None)
+        merged = cm.merged(n_total)
+        ground = cm.ground(n_total)
+        planes = cm.ground_planes()
+        return dict(res=res, out=out, cells=cells, counts=counts, merged=merged, ground=ground, planes=planes)
+    finally:
+        if own:
+            cm.close()
+
+
+def a4(a):
+    return np.stack([a["x"], a["y"], a["z"], a["intensity"]], 1)
+
+
+def check(sensors, zones, params, gp=GP):
+    want_ng, want_g, want_planes = expected(sensors, zones, params, gp)
+    g = run(sensors, zones, params, gp)
+    assert same_bits(a4(g["merged"]), xyzi_of(want_ng)), "no-ground cloud (content and order)"
+    assert same_bits(a4(g["ground"]), xyzi_of(want_g)), "ground cloud (content and order)"
+    for s, pls in enumerate(want_planes):
+        for k, pl in enumerate(pls):
+            got = g["planes"][s * 8 + k]
+            if pl is None:
+                assert got.band_points == 0 and got.found == 0
+                continue
+            assert got.found == pl.found and got.inliers == pl.n_inliers and got.iterations == pl.iterations
+            if pl.found:
+                assert np.abs(np.array(got.plane) - np.array(pl.plane)).max() <= 1e-6
+    st, vox, rep = oracle.voxelgrid(want_ng, params.leaf, params.min_points_per_voxel, stable=True)
+    assert g["res"].status == st and g["res"].n_out == len(vox) and g["res"].n_merged == len(want_ng)
+    if st == oracle.OK:
+        assert np.array_equal(g["cells"], rep.cells) and np.array_equal(g["counts"], rep.counts)
+        assert_centroids_close(a4(g["out"]), xyzi_of(vox))
+    return g, want_planes
+
+
+def test_front_sensor_five_slabs():
+    rng = np.random.default_rng(21)
+    sensors = [xyzi_cloud(scene(rng, 120_000), rng.uniform(0, 255, 120_000))]
+    params = MergeParams(leaf=(0.1,) * 3, min_points_per_voxel=2, **ROI)
+    g, planes = check(sensors, [FRONT], params)
+    for pl in planes[0]:                      # the fitted planes are the scene's ground: z = -0.05 + 0.01 x + 0.02 y
+        n = np.array(pl.plane[:3]) * np.sign(pl.plane[2])
+        assert pl.found and abs(n[0] / n[2] + 0.01) < 2e-3 and abs(n[1] / n[2] + 0.02) < 5e-3
+    assert 0 < len(g["ground"]) < 120_000 and len(g["ground"]) + len(g["merged"]) <= 120_000
+
+
+def test_four_sensors_with_poses_keep_all_slab_and_gaps():
+    rng = np.random.default_rng(22)
+    sensors = []
+    for s in range(4):
+        xyz = scene(rng, 60_000)
+        q = synth.yaw_quaternion(0.02 * (s - 1.5))
+        t = np.array([0.3 * s, -0.2 * s, 0.05 * s])
+        # put the scene into the sensor frame so that the transform brings it back (roughly) to the vehicle frame
+        from scipy.spatial.transform import Rotation as R
+        rot = R.from_quat(q).as_matrix()
+        local = ((xyz.astype(np.float64) - t) @ rot).astype(np.float32)
+        sensors.append(xyzi_cloud(local, rng.uniform(0, 255, len(local)), q_xyzw=q, t_xyz=t))
+    zones = [FRONT,
+             [(20.0, 40.0, 1.0), (-15.0, 35.0, -1.0)],             # top-middle: one plane slab, one slab kept whole (:436-444)
+             [(34.0, 26.0, 1.5), (24.0, 10.0, 1.2), (14.0, 10.0, 0.8), (4.0, 10.0, 0.5)],   # Livox (:475-497): nothing behind x = 4
+             [(30.0, 30.0, 2.0), (4.0, 26.0, 1.5), (-4.0, 8.0, 0.3), (-15.0, 11.0, 0.5)]]   # proceedRear
+    params = MergeParams(leaf=(0.1,) * 3, min_points_per_voxel=2, **ROI)
+    check(sensors, zones, params)
+
+
+def test_degenerate_bands():
+    """Empty band, two-point band (no model: nothing is ground), and a band of exactly collinear points (every
+    sample is skipped: no plane either)."""
+    rng = np.random.default_rng(23)
+    above = np.stack([rng.uniform(0, 10, 500), rng.uniform(-2, 2, 500), rng.uniform(1.0, 2.0, 500)], 1)
+    two = np.array([[12.0, 0.0, 0.0], [13.0, 1.0, 0.1]])
+    line = np.stack([np.linspace(21.0, 29.0, 64), np.zeros(64), np.zeros(64)], 1)
+    xyz = np.concatenate([above, two, line]).astype(np.float32)
+    sensors = [xyzi_cloud(xyz, np.arange(len(xyz), dtype=np.float32))]
+    zones = [[(0.0, 10.0, 0.5), (10.0, 10.0, 0.5), (20.0, 10.0, 0.5)]]
+    params = MergeParams(leaf=(0.2,) * 3, min_points_per_voxel=0, **ROI)
+    g, planes = check(sensors, zones, params)
+    assert [p.found for p in planes[0]] == [0, 0, 0]
+    assert len(g["ground"]) == 0 and len(g["merged"]) == len(xyz)
+
+
+def test_off_and_repeatable():
+    rng = np.random.default_rng(24)
+    sensors = [xyzi_cloud(scene(rng, 40_000), rng.uniform(0, 255, 40_000))]
+    params = MergeParams(leaf=(0.1,) * 3, min_points_per_voxel=2, **ROI)
+    with capi.CloudMerger(max_points_total=40_000, max_sensors=1, flags=capi.FLAG_OCCUPANCY) as cm:
+        a = run(sensors, [FRONT], params, GP, cm=cm)
+        b = run(sensors, [FRONT], params, GP, cm=cm)
+        assert same_bits(a4(a["out"]), a4(b["out"])) and same_bits(a4(a["ground"]), a4(b["ground"]))
+        cm.set_ground_removal(None)
+        cm.submit_all(sensors)
+        res = cm.merge_voxelize(params)
+        st, _, _, rep = oracle.merge_voxelize(sensors, params, stable=True)
+        assert res.n_out == rep.n_out and res.n_merged == rep.n_merged
+        with pytest.raises(capi.CloudMergeError):
+            cm.ground(10)
+
+
+def test_argument_checks():
+    sensors, params = synth.config2(n_per_sensor=1000)
+    with capi.CloudMerger(max_points_total=4000, max_sensors=4) as cm:
+        g = capi.make_ground_params([FRONT])
+        g.max_iterations = 0
+        with pytest.raises(capi.CloudMergeError):
+            cm.set_ground_removal(g)
+        g = capi.make_ground_params([FRONT])
+        g.outlier_radius = 0.15
+        with pytest.raises(capi.CloudMergeError):
+            cm.set_ground_removal(g)
+        cm.set_ground_removal(capi.make_ground_params([FRONT]))
+        params.outlier_radius = 0.15
+        cm.submit_all(sensors)
+        with pytest.raises(capi.CloudMergeError) as e:
+            cm.merge_voxelize(params)
+        assert e.value.status == capi.BAD_ARG
