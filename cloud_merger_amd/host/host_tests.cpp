@@ -87,6 +87,15 @@ static void test_reference_config() {
     CHECK(c.params.crop_min[1] == -5.0f && c.params.crop_max[1] == 5.0f);
     CHECK(c.params.crop_min[2] == -0.5f && c.params.crop_max[2] == 3.0f);
     CHECK(c.params.outlier_enable == 0);
+    const NodeConfig l = live_node_config();
+    CHECK(l.ground_enable && l.ground.max_iterations == 1000 && l.ground.distance_threshold == 0.3f && l.ground.probability == 0.99f);
+    CHECK(l.ground.n_zones[0] == 5 && l.ground.n_zones[3] == 5 && l.ground.n_zones[4] == 2 && l.ground.n_zones[5] == 4);
+    CHECK(l.ground.zones[0][0].x_min == 30.0f && l.ground.zones[0][0].x_length == 30.0f && l.ground.zones[0][0].z_max_ground == 2.5f);   // front slab
+    CHECK(l.ground.zones[0][4].x_min == -15.0f && l.ground.zones[0][4].x_length == 11.0f && l.ground.zones[0][4].z_max_ground == 0.5f);  // rear slab
+    CHECK(l.ground.zones[0][3].x_min == -4.0f && l.ground.zones[0][2].x_min == 4.0f && l.ground.zones[0][1].x_min == 19.0f);
+    CHECK(l.ground.zones[4][1].z_max_ground < 0.0f && l.ground.zones[4][1].x_min == -15.0f && l.ground.zones[4][1].x_length == 35.0f);
+    CHECK(l.ground.zones[5][0].x_min == 34.0f && l.ground.zones[5][3].x_min == 4.0f && l.ground.zones[5][3].z_max_ground == 0.5f);
+    CHECK(l.no_ground_topic == "/points_no_ground" && l.ground_topic == "/points_ground");
     const NodeConfig f = fusion_config();
     CHECK(f.params.outlier_enable == 1 && f.params.outlier_radius == 0.1f && f.params.outlier_min_neighbors == 1);
     CHECK(f.sensors.size() == 6 && f.params.crop_enable == 1);
@@ -165,6 +174,40 @@ static void test_node_without_gpu_fails_loudly(bool expect_gpu) {
         CHECK(n3.on_cloud(0, ca) == CM_OK);
         CHECK(n3.spin_once() == CM_OK && pts3 == 2 && stamp3 == 2010000000ull && n3.frames_published() == 1);
         CHECK(n3.spin_once() == CM_NOT_READY && n3.clouds_dropped_for_sync() == 1);
+        // ground removal through the node: a flat ground + a box; three topics come out
+        NodeConfig c4;
+        c4.sensors = {{"a", "/a", "/fa", true}};
+        c4.params.leaf[0] = c4.params.leaf[1] = c4.params.leaf[2] = 0.5f;
+        c4.params.downsample_all_data = 1;
+        c4.params.crop_enable = 1;
+        c4.params.crop_min[0] = -15.f; c4.params.crop_min[1] = -5.f; c4.params.crop_min[2] = -0.5f;
+        c4.params.crop_max[0] = 60.f; c4.params.crop_max[1] = 5.f; c4.params.crop_max[2] = 3.f;
+        c4.max_points_total = 1000;
+        c4.ground_enable = true;
+        c4.ground.max_iterations = 100; c4.ground.distance_threshold = 0.3f; c4.ground.probability = 0.99f;
+        c4.ground.optimize_coefficients = 1; c4.ground.z_keep_max = 3.0f; c4.ground.seed = 7;
+        c4.ground.n_zones[0] = 1; c4.ground.zones[0][0] = {0.0f, 10.0f, 0.5f};
+        CloudMergerNode n4(c4);
+        CHECK(n4.ok());
+        n4.set_transform(0, q, t);
+        size_t n_vox = 0, n_ng = 0, n_gr = 0;
+        n4.set_publisher([&](const std::string& topic, const PointCloud2& out) {
+            if (topic == "/points_voxel") n_vox = out.num_points();
+            else if (topic == "/points_no_ground") n_ng = out.num_points();
+            else if (topic == "/points_ground") n_gr = out.num_points();
+        });
+        PointCloud2 cg = make_xyzi16_message(104);
+        for (int i = 0; i < 100; ++i) {                                   // 10 x 10 ground points at z = 0.01 * (i % 3)
+            const float rec[4] = {0.5f + (i % 10), -4.5f + (i / 10), 0.01f * (i % 3), 1.f};
+            std::memcpy(cg.data.data() + i * 16, rec, 16);
+        }
+        for (int i = 0; i < 4; ++i) {                                     // a box 1.5 m above the ground
+            const float rec[4] = {5.0f + 0.1f * i, 0.0f, 1.5f, 2.f};
+            std::memcpy(cg.data.data() + (100 + i) * 16, rec, 16);
+        }
+        CHECK(n4.on_cloud(0, cg) == CM_OK);
+        CHECK(n4.spin_once() == CM_OK);
+        CHECK(n_gr == 100 && n_ng == 4 && n_vox == 1);
     } else {
         CHECK(!node.ok() && !node.error().empty());
         CHECK(node.spin_once() == CM_NO_DEVICE);

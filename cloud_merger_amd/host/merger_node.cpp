@@ -35,6 +35,43 @@ NodeConfig reference_config() {
     return c;
 }
 
+NodeConfig live_node_config() {
+    NodeConfig c = reference_config();
+    c.ground_enable = true;
+    cm_ground_params& g = c.ground;
+    g.max_iterations = 1000;                       // Parameter.h:38
+    g.distance_threshold = 0.3f;                   // :40
+    g.probability = 0.99f;                         // :41
+    g.optimize_coefficients = 1;                   // :95
+    g.z_keep_max = 3.0f;                           // roi_z_max, :35
+    g.seed = 12345;
+    const float roi_mid = 15.0f;
+    // proceedFront (:228-269), in its processing order: front, mid2, mid, vehicle, rear (Parameter.h:45-55)
+    const float vf_front = 30.0f, vf_mid = 15.0f, vf_mid2 = 11.0f, vf_veh = 8.0f, vf_rear = 11.0f;
+    const cm_zone front[5] = {
+        {-roi_mid + vf_rear + vf_veh + vf_mid + vf_mid2, vf_front, 2.5f},
+        {-roi_mid + vf_rear + vf_veh + vf_mid, vf_mid2, 2.0f},
+        {-roi_mid + vf_rear + vf_veh, vf_mid, 1.5f},
+        {-roi_mid + vf_rear, vf_veh, 0.3f},
+        {-roi_mid, vf_rear, 0.5f}};
+    for (int s = 0; s < 4; ++s) {                  // all four corner Velodynes go through proceedFront (:326,:352,:378,:404)
+        g.n_zones[s] = 5;
+        for (int z = 0; z < 5; ++z) g.zones[s][z] = front[z];
+    }
+    // top middle (:436-444): one slab with a plane, the part behind it kept whole (Parameter.h:66-68)
+    g.n_zones[4] = 2;
+    g.zones[4][0] = {20.0f, 40.0f, 1.0f};
+    g.zones[4][1] = {-roi_mid, roi_mid + 20.0f, -1.0f};
+    // Livox (:475-497): front, mid2, mid, rear (Parameter.h:71-80)
+    const float l_front = 26.0f, l_mid = 10.0f, l_mid2 = 10.0f, l_rear = 10.0f, l_dev = 4.0f;
+    g.n_zones[5] = 4;
+    g.zones[5][0] = {l_dev + l_rear + l_mid + l_mid2, l_front, 1.5f};
+    g.zones[5][1] = {l_dev + l_rear + l_mid, l_mid2, 1.2f};
+    g.zones[5][2] = {l_dev + l_rear, l_mid, 0.8f};
+    g.zones[5][3] = {l_dev, l_rear, 0.5f};
+    return c;
+}
+
 NodeConfig fusion_config() {
     // my_cloud_fusion/src/cloud_fusion_node.cpp:72-75: remove_outliers, then voxelgrid, on the
     // fused cloud; constants from my_cloud_fusion/src/Parameter.h:15-16,109-110.
@@ -79,6 +116,18 @@ bool load_config(const std::string& path, NodeConfig* cfg, std::string* err) {
         else if (key == "outlier") { ok = static_cast<bool>(is >> c.params.outlier_radius >> c.params.outlier_min_neighbors); c.params.outlier_enable = 1; }
         else if (key == "stamp_from_inputs") { int v; ok = static_cast<bool>(is >> v); c.stamp_from_inputs = v != 0; }
         else if (key == "max_stamp_spread_ms") { double v; ok = static_cast<bool>(is >> v) && v >= 0; c.max_stamp_spread_ns = static_cast<uint64_t>(v * 1e6); }
+        else if (key == "ground") {
+            ok = static_cast<bool>(is >> c.ground.max_iterations >> c.ground.distance_threshold >> c.ground.probability);
+            c.ground.optimize_coefficients = 1; c.ground.z_keep_max = c.params.crop_max[2]; c.ground.seed = 12345;
+            c.ground_enable = true;
+        } else if (key == "zone") {
+            std::string name; cm_zone z{};
+            ok = static_cast<bool>(is >> name >> z.x_min >> z.x_length >> z.z_max_ground);
+            size_t sidx = c.sensors.size();
+            for (size_t q = 0; q < c.sensors.size(); ++q) if (c.sensors[q].name == name) sidx = q;
+            ok = ok && sidx < c.sensors.size() && c.ground.n_zones[sidx] < CM_MAX_ZONES;
+            if (ok) c.ground.zones[sidx][c.ground.n_zones[sidx]++] = z;
+        }
         else if (key == "max_points_total") ok = static_cast<bool>(is >> c.max_points_total);
         else if (key == "device") ok = static_cast<bool>(is >> c.device);
         else ok = false;
@@ -110,6 +159,13 @@ CloudMergerNode::CloudMergerNode(const NodeConfig& cfg)
     if (st != CM_OK) {
         ctx_ = nullptr;
         error_ = std::string("cm_create: ") + cm_status_string(st);
+    } else if (cfg_.ground_enable) {
+        const int gs = cm_set_ground_removal(ctx_, &cfg_.ground);
+        if (gs != CM_OK) {
+            error_ = std::string("cm_set_ground_removal: ") + cm_last_error(ctx_);
+            cm_destroy(ctx_);
+            ctx_ = nullptr;
+        }
     }
     clock_ = [] {
         return static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(
@@ -192,6 +248,19 @@ int CloudMergerNode::spin_once(cm_result* res) {
     for (const auto& t : stamp_ns_) newest = std::max(newest, t.load());
     msg.header.stamp_ns = (cfg_.stamp_from_inputs && newest) ? newest : clock_();
     msg.header.frame_id = cfg_.base_frame;
+    if (cfg_.ground_enable && publish_ && st != CM_EMPTY_INPUT) {
+        // publishPointcloud's other two legs (:203-213): the fused no-ground and ground clouds
+        for (int leg = 0; leg < 2; ++leg) {
+            uint64_t n = 0;
+            PointCloud2 m2 = make_xyzi16_message(static_cast<size_t>(r.n_in));
+            const int cs = leg == 0 ? cm_merged_copy(ctx_, m2.data.data(), r.n_in, &n) : cm_ground_copy(ctx_, m2.data.data(), r.n_in, &n);
+            if (cs != CM_OK) { error_ = cm_last_error(ctx_); return cs; }
+            m2.width = static_cast<uint32_t>(n); m2.height = n ? 1 : 0; m2.row_step = static_cast<uint32_t>(n) * m2.point_step;
+            m2.data.resize(static_cast<size_t>(n) * m2.point_step);
+            m2.header = msg.header;
+            publish_(leg == 0 ? cfg_.no_ground_topic : cfg_.ground_topic, m2);
+        }
+    }
     if (publish_) publish_(cfg_.voxel_topic, msg);
     frames_.fetch_add(1);
     return st;

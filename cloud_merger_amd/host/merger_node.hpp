@@ -44,6 +44,12 @@ struct NodeConfig {
     // required sensors' clouds lie within this many nanoseconds of each other; if they do not, the oldest
     // cloud is dropped and the tick is skipped, so that sensor's next cloud can complete the set.
     uint64_t max_stamp_spread_ns = 0;
+    // Zone-wise ground removal before the fuse (cm_set_ground_removal). Off in
+    // reference_config() (the north-star path); live_node_config() switches it on with the reference's slabs.
+    bool ground_enable = false;
+    cm_ground_params ground{};
+    std::string no_ground_topic = "/points_no_ground";   // :516
+    std::string ground_topic = "/points_ground";          // :517
 };
 
 // Loads a node description from a text file (an N-sensor configuration instead
@@ -52,12 +58,18 @@ struct NodeConfig {
 //   base_frame <id> | voxel_topic <topic> | rate_hz <v> | leaf <v> | min_points_per_voxel <n>
 //   crop <x0> <y0> <z0> <x1> <y1> <z1> | outlier <radius> <min_neighbors> | stamp_from_inputs <0|1>
 //   max_points_total <n> | device <n> | max_stamp_spread_ms <v>
+//   ground <max_iterations> <distance_threshold> <probability> | zone <sensor_name> <x_min> <x_length> <z_max_ground>
 // Starts from reference_config() minus its sensors when the file names any. Returns false + *err.
 bool load_config(const std::string& path, NodeConfig* cfg, std::string* err);
 
 // The reference's literals: six sensors in fuse order fr, fl, rr, rl, tm, livox (:137-142), ROI
 // crop (Parameter.h:31-35), leaf 0.1 m, min 2 points per voxel (Parameter.h:27-28).
 NodeConfig reference_config();
+// The live node as a whole (pcl_preprocessing): reference_config() plus the zone-wise ground removal of its
+// callbacks — proceedFront for the four corner Velodynes (:228-269, called at :326,:352,:378,:404; proceedRear
+// :277-312 is defined but never called), the top-middle slabs (:436-444), the Livox
+// slabs (:475-497) — with Parameter.h:38-81's numbers. Publishes /points_no_ground and /points_ground as well.
+NodeConfig live_node_config();
 // The class-based variant (my_cloud_fusion): same sensors and ROI, plus radius outlier removal on the
 // fused cloud before VoxelGrid (cloud_fusion_node.cpp:72-75).
 NodeConfig fusion_config();
