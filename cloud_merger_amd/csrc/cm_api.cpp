@@ -98,6 +98,8 @@ struct cm_ctx {
     unsigned char* gmask = nullptr;      // ground points of the last frame (padded index space)
     uint32_t* zone_off = nullptr;
     CmGroundPlaneDev* d_planes = nullptr;
+    void* hyp0 = nullptr;                // first round of hypotheses of every slab: planes, validity, inlier counts
+    uint32_t *valid0 = nullptr, *counts0 = nullptr;
     bool frame_had_ground = false;
 
     // bucket path (cm_kernels_v2.hip)
@@ -216,7 +218,7 @@ void free_all(cm_ctx* c) {
     F(c->keys_a); F(c->keys_b); F(c->vals_a); F(c->vals_b); F(c->hist); F(c->totals);
     F(c->seg_counts); F(c->seg_tile_counts); F(c->seg_groups); F(c->grp); F(c->partials); F(c->out_key); F(c->out_cnt); F(c->merged_total); F(c->out); F(c->merged); F(c->partial); F(c->table_entries); F(c->mask); F(c->sorted_pts); F(c->rows); F(c->d_state_o);
     F(c->rec_a); F(c->rec_b); F(c->dig); F(c->tile_state); F(c->records);
-    F(c->d_ground); F(c->d_state_g); F(c->gmask); F(c->zone_off); F(c->d_planes);
+    F(c->d_ground); F(c->d_state_g); F(c->gmask); F(c->zone_off); F(c->d_planes); F(c->hyp0); F(c->valid0); F(c->counts0);
     F(c->d_frame); F(c->d_state[0]); F(c->d_state[1]);
     if (c->h_state) (void)hipHostFree(c->h_state);
     for (auto& s : c->slots) {
@@ -604,6 +606,12 @@ int launch_classic(cm_ctx* c, const cm_params* p, int mode, int grid_mode, uint3
         if (!c->d_state_g) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_state_g), sizeof(CmFrameState)));
         if (!c->zone_off) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->zone_off), (CM_DEV_MAX_SENSORS * CM_DEV_MAX_ZONES + 1) * 4));
         if (!c->d_planes) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_planes), CM_DEV_MAX_SENSORS * CM_DEV_MAX_ZONES * sizeof(CmGroundPlaneDev)));
+        {
+            const size_t nh = static_cast<size_t>(CM_DEV_MAX_SENSORS) * CM_DEV_MAX_ZONES * CM_GROUND_BATCH;
+            if (!c->hyp0) HIP_TRY(c, hipMalloc(&c->hyp0, nh * 16));
+            if (!c->valid0) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->valid0), nh * 4));
+            if (!c->counts0) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->counts0), nh * 4));
+        }
         if (!c->ground_uploaded) { cmkg_setup(st, c->ground, c->d_ground); c->ground_uploaded = true; }
         HIP_TRY(c, hipMemsetAsync(c->d_state_g, 0, sizeof(CmFrameState), st));
         HIP_TRY(c, hipMemsetAsync(c->mask, 0, f.n_padded, st));
@@ -619,8 +627,8 @@ int launch_classic(cm_ctx* c, const cm_params* p, int mode, int grid_mode, uint3
         cmk_scatter(st, c->d_state_g, c->keys_a, c->vals_a, c->keys_b, c->vals_b, c->hist, grp0, big ? c->totals : nullptr, 0, nt,
                     n_groups, f.n_padded, c->lds_rank);
         prof_mark(c, "kg_ransac");
-        cmkg_planes(st, c->d_frame, c->d_ground, c->d_state_g, c->keys_b, c->vals_b, c->sorted_pts, c->zone_off, c->d_planes,
-                    c->mask, c->gmask, f.n_padded);
+        cmkg_planes(st, c->d_frame, c->d_ground, c->d_state_g, c->keys_b, c->vals_b, c->sorted_pts, c->zone_off, c->hyp0,
+                    c->valid0, c->counts0, c->d_planes, c->mask, c->gmask, f.n_padded);
         c->frame_mask = c->mask;
         c->frame_had_ground = true;
     }

@@ -220,9 +220,10 @@ __global__ __launch_bounds__(256) void kg_ransac(const CmGroundDev* __restrict__
                                                  const CmFrameState* __restrict__ st,
                                                  const float4* __restrict__ band_pts,
                                                  const uint32_t* __restrict__ zone_off,
-                                                 CmGroundPlaneDev* __restrict__ planes,
-                                                 unsigned char* __restrict__ keep_mask,
-                                                 unsigned char* __restrict__ ground_mask) {
+                                                 const float4* __restrict__ hyp0,
+                                                 const uint32_t* __restrict__ valid0,
+                                                 const uint32_t* __restrict__ counts0,
+                                                 CmGroundPlaneDev* __restrict__ planes) {
     __shared__ float s_pl[CM_GROUND_BATCH][4];
     __shared__ uint32_t s_valid[CM_GROUND_BATCH];
     __shared__ uint32_t s_cnt[CM_GROUND_BATCH];
@@ -240,11 +241,7 @@ __global__ __launch_bounds__(256) void kg_ransac(const CmGroundDev* __restrict__
         o.plane[0] = o.plane[1] = o.plane[2] = o.plane[3] = 0.f;
         o.band_points = n; o.inliers = 0; o.iterations = 0; o.found = 0;
     }
-    if (n == 0) return;
-    if (n < 3) {                                          // PCL: not enough points for a model — nothing is ground
-        for (uint32_t i = threadIdx.x; i < n; i += 256) keep_mask[__float_as_uint(pts[i].w)] = 1;
-        return;
-    }
+    if (n < 3) return;                                    // PCL: not enough points for a model — found stays 0
     const uint32_t max_iter = gd->max_iterations;
     const uint32_t J = max_iter + CM_GROUND_SPARE;
     // PCL's loop state (thread 0)
@@ -253,6 +250,16 @@ __global__ __launch_bounds__(256) void kg_ransac(const CmGroundDev* __restrict__
     double pno = 1.0, pw = 1.0;
     const double stop = __dsub_rn(1.0, static_cast<double>(gd->probability));
     for (uint32_t j0 = 0; j0 < J; j0 += CM_GROUND_BATCH) {
+        if (j0 == 0) {
+            // the first round was scored by kg_score0, all slabs at once
+            if (threadIdx.x < CM_GROUND_BATCH) {
+                const float4 h = hyp0[zone * CM_GROUND_BATCH + threadIdx.x];
+                s_pl[threadIdx.x][0] = h.x; s_pl[threadIdx.x][1] = h.y; s_pl[threadIdx.x][2] = h.z; s_pl[threadIdx.x][3] = h.w;
+                s_valid[threadIdx.x] = valid0[zone * CM_GROUND_BATCH + threadIdx.x];
+                s_cnt[threadIdx.x] = counts0[zone * CM_GROUND_BATCH + threadIdx.x];
+            }
+            __syncthreads();
+        } else {
         if (threadIdx.x < CM_GROUND_BATCH) {
             const uint32_t j = j0 + threadIdx.x;
             uint32_t idx[3];
@@ -282,6 +289,7 @@ __global__ __launch_bounds__(256) void kg_ransac(const CmGroundDev* __restrict__
         }
         if (lane < CM_GROUND_BATCH && mine) atomicAdd(&s_cnt[lane], mine);
         __syncthreads();
+        }
         if (threadIdx.x == 0) {
             bool go = true;
             for (int h = 0; h < CM_GROUND_BATCH && go; ++h) {
@@ -314,8 +322,7 @@ __global__ __launch_bounds__(256) void kg_ransac(const CmGroundDev* __restrict__
         __syncthreads();
         if (!s_go) break;
     }
-    if (!s_found) {                                        // no valid sample at all: nothing is ground
-        for (uint32_t i = threadIdx.x; i < n; i += 256) keep_mask[__float_as_uint(pts[i].w)] = 1;
+    if (!s_found) {                                        // no valid sample at all: no plane
         if (threadIdx.x == 0) planes[zone].iterations = s_iter;
         return;
     }
@@ -323,15 +330,21 @@ __global__ __launch_bounds__(256) void kg_ransac(const CmGroundDev* __restrict__
     // optimizeModelCoefficients: least-squares plane through the inliers (more than 3 of them)
     if (gd->optimize) {
         double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (uint32_t i = threadIdx.x; i < n; i += 256) {  // element i -> partial i mod 256, in order
-            const float4 p = pts[i];
-            if (plane_inlier(a, b, c, d, p, thr)) {
-                const double x = p.x, y = p.y, z = p.z;
-                acc[0] = __dadd_rn(acc[0], x); acc[1] = __dadd_rn(acc[1], y); acc[2] = __dadd_rn(acc[2], z);
-                acc[3] = __dadd_rn(acc[3], __dmul_rn(x, x)); acc[4] = __dadd_rn(acc[4], __dmul_rn(x, y));
-                acc[5] = __dadd_rn(acc[5], __dmul_rn(x, z)); acc[6] = __dadd_rn(acc[6], __dmul_rn(y, y));
-                acc[7] = __dadd_rn(acc[7], __dmul_rn(y, z)); acc[8] = __dadd_rn(acc[8], __dmul_rn(z, z));
-                acc[9] = __dadd_rn(acc[9], 1.0);
+        for (uint32_t i4 = threadIdx.x; i4 < n; i4 += 1024) {   // element i -> partial i mod 256, in order; four loads in flight
+            float4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = (i4 + u * 256 < n) ? pts[i4 + u * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 p = q[u];
+                if (i4 + u * 256 < n && plane_inlier(a, b, c, d, p, thr)) {
+                    const double x = p.x, y = p.y, z = p.z;
+                    acc[0] = __dadd_rn(acc[0], x); acc[1] = __dadd_rn(acc[1], y); acc[2] = __dadd_rn(acc[2], z);
+                    acc[3] = __dadd_rn(acc[3], __dmul_rn(x, x)); acc[4] = __dadd_rn(acc[4], __dmul_rn(x, y));
+                    acc[5] = __dadd_rn(acc[5], __dmul_rn(x, z)); acc[6] = __dadd_rn(acc[6], __dmul_rn(y, y));
+                    acc[7] = __dadd_rn(acc[7], __dmul_rn(y, z)); acc[8] = __dadd_rn(acc[8], __dmul_rn(z, z));
+                    acc[9] = __dadd_rn(acc[9], 1.0);
+                }
             }
         }
         for (int k = 0; k < 10; ++k) s_part[threadIdx.x][k] = acc[k];
@@ -366,25 +379,111 @@ __global__ __launch_bounds__(256) void kg_ransac(const CmGroundDev* __restrict__
         __syncthreads();
         a = s_best[0]; b = s_best[1]; c = s_best[2]; d = s_best[3];
     }
-    // final inliers -> ground; the rest of the band -> kept (no ground)
-    uint32_t ni = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        const float4 p = pts[i];
-        const uint32_t slot = __float_as_uint(p.w);
-        if (plane_inlier(a, b, c, d, p, thr)) { ground_mask[slot] = 1; ++ni; }
-        else keep_mask[slot] = 1;
-    }
-    ni = wave_sum_u32(ni);
-    __syncthreads();
-    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    if (lane == 0) atomicAdd(&s_cnt[0], ni);
-    __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) {                                // kg_apply classifies the band points with it
         CmGroundPlaneDev& o = planes[zone];
         o.plane[0] = a; o.plane[1] = b; o.plane[2] = c; o.plane[3] = d;
-        o.inliers = s_cnt[0]; o.iterations = s_iter; o.found = 1;
+        o.iterations = s_iter; o.found = 1;
         (void)best_j;
+    }
+}
+
+// First round of hypotheses of every slab (thread = hypothesis), so that their scoring runs over all band
+// points at once instead of slab by slab.
+__global__ __launch_bounds__(64) void kg_hyp0(const CmGroundDev* __restrict__ gd, const CmFrameState* __restrict__ st,
+                                              const float4* __restrict__ band_pts, const uint32_t* __restrict__ zone_off,
+                                              float4* __restrict__ hyp0, uint32_t* __restrict__ valid0,
+                                              uint32_t* __restrict__ counts0) {
+    const uint32_t zone = blockIdx.x;
+    if (threadIdx.x >= CM_GROUND_BATCH) return;
+    const uint32_t z0 = zone_off[zone], z1 = zone_off[zone + 1];
+    const uint32_t n = (st->status == CM_DEV_OK) ? z1 - z0 : 0u;
+    float pl[4] = {0.f, 0.f, 0.f, 0.f};
+    bool ok = false;
+    const uint32_t j = threadIdx.x;
+    if (n >= 3 && j < gd->max_iterations + CM_GROUND_SPARE) {
+        uint32_t idx[3];
+        sample3(gd->seed, zone, j, n, idx);
+        ok = plane_from_3(band_pts[z0 + idx[0]], band_pts[z0 + idx[1]], band_pts[z0 + idx[2]], pl);
+    }
+    hyp0[zone * CM_GROUND_BATCH + j] = make_float4(pl[0], pl[1], pl[2], pl[3]);
+    valid0[zone * CM_GROUND_BATCH + j] = ok ? 1u : 0u;
+    counts0[zone * CM_GROUND_BATCH + j] = 0;
+}
+
+// Inlier counts of those hypotheses: a workgroup takes 1024 consecutive band points (slab order), which belong
+// to one slab or a few; per slab it loads the 32 planes and counts by wave ballots.
+__global__ __launch_bounds__(CM_BLOCK) void kg_score0(const CmGroundDev* __restrict__ gd, const CmFrameState* __restrict__ st,
+                                                      const float4* __restrict__ band_pts, const uint32_t* __restrict__ keys_sorted,
+                                                      const float4* __restrict__ hyp0, uint32_t* __restrict__ counts0) {
+    __shared__ float s_pl[CM_GROUND_BATCH][4];
+    __shared__ uint32_t s_cnt[CM_GROUND_BATCH];
+    if (st->status != CM_DEV_OK) return;
+    const uint32_t n = st->n_valid;
+    const uint32_t base = blockIdx.x * 1024u;
+    if (base >= n) return;
+    const uint32_t end = min(base + 1024u, n);
+    const int lane = threadIdx.x & 63;
+    const float thr = gd->threshold;
+    float4 p[4];
+    uint32_t zk[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t i = base + u * 256 + threadIdx.x;
+        p[u] = i < end ? band_pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        zk[u] = i < end ? keys_sorted[i] : 0xFFFFFFFFu;
+    }
+    const uint32_t z_first = keys_sorted[base], z_last = keys_sorted[end - 1];
+    for (uint32_t zone = z_first; zone <= z_last; ++zone) {       // slabs present in this chunk (ascending keys)
+        __syncthreads();
+        if (threadIdx.x < CM_GROUND_BATCH) {
+            const float4 h = hyp0[zone * CM_GROUND_BATCH + threadIdx.x];
+            s_pl[threadIdx.x][0] = h.x; s_pl[threadIdx.x][1] = h.y; s_pl[threadIdx.x][2] = h.z; s_pl[threadIdx.x][3] = h.w;
+            s_cnt[threadIdx.x] = 0;
+        }
+        __syncthreads();
+        uint32_t mine = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool have = zk[u] == zone;
+            if (__ballot(have) == 0ull) continue;                 // wave-uniform
+#pragma unroll 8
+            for (int h = 0; h < CM_GROUND_BATCH; ++h) {
+                const bool in = have && plane_inlier(s_pl[h][0], s_pl[h][1], s_pl[h][2], s_pl[h][3], p[u], thr);
+                const uint32_t c = static_cast<uint32_t>(__popcll(__ballot(in)));
+                if (lane == h) mine += c;
+            }
+        }
+        if (lane < CM_GROUND_BATCH && mine) atomicAdd(&s_cnt[lane], mine);
+        __syncthreads();
+        if (threadIdx.x < CM_GROUND_BATCH && s_cnt[threadIdx.x])
+            atomicAdd(&counts0[zone * CM_GROUND_BATCH + threadIdx.x], s_cnt[threadIdx.x]);
+    }
+}
+
+// Every band point against its slab's plane: inliers are ground, the rest of the band is kept.
+__global__ __launch_bounds__(CM_BLOCK) void kg_apply(const CmGroundDev* __restrict__ gd, const CmFrameState* __restrict__ st,
+                                                     const float4* __restrict__ band_pts, const uint32_t* __restrict__ keys_sorted,
+                                                     CmGroundPlaneDev* __restrict__ planes,
+                                                     unsigned char* __restrict__ keep_mask, unsigned char* __restrict__ ground_mask) {
+    if (st->status != CM_DEV_OK) return;
+    const uint32_t n = st->n_valid;
+    const float thr = gd->threshold;
+    for (uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x; i < n; i += gridDim.x * CM_BLOCK) {
+        const float4 p = band_pts[i];
+        const uint32_t zone = keys_sorted[i];
+        const CmGroundPlaneDev& pl = planes[zone];
+        const bool in = pl.found && plane_inlier(pl.plane[0], pl.plane[1], pl.plane[2], pl.plane[3], p, thr);
+        const uint32_t slot = __float_as_uint(p.w);
+        if (in) ground_mask[slot] = 1; else keep_mask[slot] = 1;
+        // inlier count of the slab: one add per wave where the whole wave sits in one slab (almost always)
+        const uint32_t z_lead = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(zone)));
+        const unsigned long long active = __ballot(true);
+        if (__ballot(zone == z_lead) == active) {
+            const uint32_t c = static_cast<uint32_t>(__popcll(__ballot(in)));
+            if (c && (threadIdx.x & 63) == static_cast<uint32_t>(__builtin_ctzll(active))) atomicAdd(&planes[zone].inliers, c);
+        } else if (in) {
+            atomicAdd(&planes[zone].inliers, 1u);
+        }
     }
 }
 
@@ -401,10 +500,15 @@ void cmkg_classify(hipStream_t s, const CmFrameDev* fd, const CmGroundDev* gd, C
 }
 void cmkg_planes(hipStream_t s, const CmFrameDev* fd, const CmGroundDev* gd, const CmFrameState* st,
                  const uint32_t* keys_sorted, const uint32_t* vals_sorted, void* band_pts, uint32_t* zone_off,
-                 CmGroundPlaneDev* planes, unsigned char* keep_mask, unsigned char* ground_mask, uint32_t n_padded) {
+                 void* hyp0, uint32_t* valid0, uint32_t* counts0, CmGroundPlaneDev* planes, unsigned char* keep_mask,
+                 unsigned char* ground_mask, uint32_t n_padded) {
     const uint32_t blocks = (n_padded + CM_BLOCK * 4 - 1) / (CM_BLOCK * 4);
-    hipLaunchKernelGGL(kg_gather, dim3(blocks), dim3(CM_BLOCK), 0, s, fd, st, keys_sorted, vals_sorted,
-                       reinterpret_cast<float4*>(band_pts), zone_off);
-    hipLaunchKernelGGL(kg_ransac, dim3(CM_DEV_MAX_SENSORS * CM_DEV_MAX_ZONES), dim3(256), 0, s, gd, st,
-                       reinterpret_cast<const float4*>(band_pts), zone_off, planes, keep_mask, ground_mask);
+    const uint32_t zones = CM_DEV_MAX_SENSORS * CM_DEV_MAX_ZONES;
+    float4* bp = reinterpret_cast<float4*>(band_pts);
+    float4* h0 = reinterpret_cast<float4*>(hyp0);
+    hipLaunchKernelGGL(kg_gather, dim3(blocks), dim3(CM_BLOCK), 0, s, fd, st, keys_sorted, vals_sorted, bp, zone_off);
+    hipLaunchKernelGGL(kg_hyp0, dim3(zones), dim3(64), 0, s, gd, st, bp, zone_off, h0, valid0, counts0);
+    hipLaunchKernelGGL(kg_score0, dim3(blocks), dim3(CM_BLOCK), 0, s, gd, st, bp, keys_sorted, h0, counts0);
+    hipLaunchKernelGGL(kg_ransac, dim3(zones), dim3(256), 0, s, gd, st, bp, zone_off, h0, valid0, counts0, planes);
+    hipLaunchKernelGGL(kg_apply, dim3(blocks), dim3(CM_BLOCK), 0, s, gd, st, bp, keys_sorted, planes, keep_mask, ground_mask);
 }
