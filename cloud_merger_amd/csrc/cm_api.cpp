@@ -100,6 +100,7 @@ struct cm_ctx {
     CmGroundPlaneDev* d_planes = nullptr;
     void* hyp0 = nullptr;                // first round of hypotheses of every slab: planes, validity, inlier counts
     uint32_t *valid0 = nullptr, *counts0 = nullptr;
+    double* chunk_sums = nullptr;        // least-squares sums per chunk of band points
     bool frame_had_ground = false;
 
     // bucket path (cm_kernels_v2.hip)
@@ -218,7 +219,7 @@ void free_all(cm_ctx* c) {
     F(c->keys_a); F(c->keys_b); F(c->vals_a); F(c->vals_b); F(c->hist); F(c->totals);
     F(c->seg_counts); F(c->seg_tile_counts); F(c->seg_groups); F(c->grp); F(c->partials); F(c->out_key); F(c->out_cnt); F(c->merged_total); F(c->out); F(c->merged); F(c->partial); F(c->table_entries); F(c->mask); F(c->sorted_pts); F(c->rows); F(c->d_state_o);
     F(c->rec_a); F(c->rec_b); F(c->dig); F(c->tile_state); F(c->records);
-    F(c->d_ground); F(c->d_state_g); F(c->gmask); F(c->zone_off); F(c->d_planes); F(c->hyp0); F(c->valid0); F(c->counts0);
+    F(c->d_ground); F(c->d_state_g); F(c->gmask); F(c->zone_off); F(c->d_planes); F(c->hyp0); F(c->valid0); F(c->counts0); F(c->chunk_sums);
     F(c->d_frame); F(c->d_state[0]); F(c->d_state[1]);
     if (c->h_state) (void)hipHostFree(c->h_state);
     for (auto& s : c->slots) {
@@ -611,6 +612,7 @@ int launch_classic(cm_ctx* c, const cm_params* p, int mode, int grid_mode, uint3
             if (!c->hyp0) HIP_TRY(c, hipMalloc(&c->hyp0, nh * 16));
             if (!c->valid0) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->valid0), nh * 4));
             if (!c->counts0) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->counts0), nh * 4));
+            if (!c->chunk_sums) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->chunk_sums), (static_cast<size_t>(c->cap_padded) / CM_GROUND_CHUNK + CM_DEV_MAX_SENSORS * CM_DEV_MAX_ZONES + 1) * 10 * sizeof(double)));
         }
         if (!c->ground_uploaded) { cmkg_setup(st, c->ground, c->d_ground); c->ground_uploaded = true; }
         HIP_TRY(c, hipMemsetAsync(c->d_state_g, 0, sizeof(CmFrameState), st));
@@ -628,7 +630,7 @@ int launch_classic(cm_ctx* c, const cm_params* p, int mode, int grid_mode, uint3
                     n_groups, f.n_padded, c->lds_rank);
         prof_mark(c, "kg_ransac");
         cmkg_planes(st, c->d_frame, c->d_ground, c->d_state_g, c->keys_b, c->vals_b, c->sorted_pts, c->zone_off, c->hyp0,
-                    c->valid0, c->counts0, c->d_planes, c->mask, c->gmask, f.n_padded);
+                    c->valid0, c->counts0, c->chunk_sums, c->d_planes, c->mask, c->gmask, f.n_padded);
         c->frame_mask = c->mask;
         c->frame_had_ground = true;
     }

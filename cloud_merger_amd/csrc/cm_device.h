@@ -80,6 +80,7 @@ struct CmFrameDev {
 // Zone-wise ground removal (cm_kernels_ground.hip): per sensor up to 8 x-slabs, each with a z band.
 #define CM_DEV_MAX_ZONES 8
 #define CM_GROUND_BATCH 32        // RANSAC hypotheses scored per round (PCL's loop usually stops within the first)
+#define CM_GROUND_CHUNK 8192      // band points per workgroup of the least-squares sums (fixed: it defines their order)
 #define CM_GROUND_SPARE 24        // hypotheses beyond max_iterations, for collinear samples that are skipped
 struct CmGroundDev {
     uint32_t n_zones[CM_DEV_MAX_SENSORS];

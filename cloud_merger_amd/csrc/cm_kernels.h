@@ -65,5 +65,5 @@ void cmkg_classify(hipStream_t s, const CmFrameDev* fd, const CmGroundDev* gd, C
 // slab offsets + band points in slab order, then one RANSAC workgroup per slab -> keep / ground masks
 void cmkg_planes(hipStream_t s, const CmFrameDev* fd, const CmGroundDev* gd, const CmFrameState* st,
                  const uint32_t* keys_sorted, const uint32_t* vals_sorted, void* band_pts, uint32_t* zone_off,
-                 void* hyp0, uint32_t* valid0, uint32_t* counts0, CmGroundPlaneDev* planes, unsigned char* keep_mask,
-                 unsigned char* ground_mask, uint32_t n_padded);
+                 void* hyp0, uint32_t* valid0, uint32_t* counts0, double* chunk_sums, CmGroundPlaneDev* planes,
+                 unsigned char* keep_mask, unsigned char* ground_mask, uint32_t n_padded);

@@ -227,7 +227,6 @@ __global__ __launch_bounds__(256) void kg_ransac(const CmGroundDev* __restrict__
     __shared__ float s_pl[CM_GROUND_BATCH][4];
     __shared__ uint32_t s_valid[CM_GROUND_BATCH];
     __shared__ uint32_t s_cnt[CM_GROUND_BATCH];
-    __shared__ double s_part[256][10];
     __shared__ float s_best[4];
     __shared__ uint32_t s_go, s_found, s_iter;
     const uint32_t zone = blockIdx.x;
@@ -326,64 +325,111 @@ __global__ __launch_bounds__(256) void kg_ransac(const CmGroundDev* __restrict__
         if (threadIdx.x == 0) planes[zone].iterations = s_iter;
         return;
     }
-    float a = s_best[0], b = s_best[1], c = s_best[2], d = s_best[3];
-    // optimizeModelCoefficients: least-squares plane through the inliers (more than 3 of them)
-    if (gd->optimize) {
-        double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (uint32_t i4 = threadIdx.x; i4 < n; i4 += 1024) {   // element i -> partial i mod 256, in order; four loads in flight
-            float4 q[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) q[u] = (i4 + u * 256 < n) ? pts[i4 + u * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float4 p = q[u];
-                if (i4 + u * 256 < n && plane_inlier(a, b, c, d, p, thr)) {
-                    const double x = p.x, y = p.y, z = p.z;
-                    acc[0] = __dadd_rn(acc[0], x); acc[1] = __dadd_rn(acc[1], y); acc[2] = __dadd_rn(acc[2], z);
-                    acc[3] = __dadd_rn(acc[3], __dmul_rn(x, x)); acc[4] = __dadd_rn(acc[4], __dmul_rn(x, y));
-                    acc[5] = __dadd_rn(acc[5], __dmul_rn(x, z)); acc[6] = __dadd_rn(acc[6], __dmul_rn(y, y));
-                    acc[7] = __dadd_rn(acc[7], __dmul_rn(y, z)); acc[8] = __dadd_rn(acc[8], __dmul_rn(z, z));
-                    acc[9] = __dadd_rn(acc[9], 1.0);
-                }
-            }
-        }
-        for (int k = 0; k < 10; ++k) s_part[threadIdx.x][k] = acc[k];
-        __syncthreads();
-        for (int stride = 128; stride > 0; stride >>= 1) {
-            if (static_cast<int>(threadIdx.x) < stride)
-                for (int k = 0; k < 10; ++k) s_part[threadIdx.x][k] = __dadd_rn(s_part[threadIdx.x][k], s_part[threadIdx.x + stride][k]);
-            __syncthreads();
-        }
-        if (threadIdx.x == 0 && s_part[0][9] > 3.0) {
-            const double* S = s_part[0];
-            const double cnt = S[9];
-            const double mx = __ddiv_rn(S[0], cnt), my = __ddiv_rn(S[1], cnt), mz = __ddiv_rn(S[2], cnt);
-            double A[3][3], V[3][3];
-            A[0][0] = __dsub_rn(__ddiv_rn(S[3], cnt), __dmul_rn(mx, mx)); A[0][1] = __dsub_rn(__ddiv_rn(S[4], cnt), __dmul_rn(mx, my));
-            A[0][2] = __dsub_rn(__ddiv_rn(S[5], cnt), __dmul_rn(mx, mz)); A[1][1] = __dsub_rn(__ddiv_rn(S[6], cnt), __dmul_rn(my, my));
-            A[1][2] = __dsub_rn(__ddiv_rn(S[7], cnt), __dmul_rn(my, mz)); A[2][2] = __dsub_rn(__ddiv_rn(S[8], cnt), __dmul_rn(mz, mz));
-            A[1][0] = A[0][1]; A[2][0] = A[0][2]; A[2][1] = A[1][2];
-            jacobi3(A, V);
-            int m = 0;
-            if (A[1][1] < A[m][m]) m = 1;
-            if (A[2][2] < A[m][m]) m = 2;
-            double nx = V[0][m], ny = V[1][m], nz = V[2][m];
-            const double len = __dsqrt_rn(__dadd_rn(__dadd_rn(__dmul_rn(nx, nx), __dmul_rn(ny, ny)), __dmul_rn(nz, nz)));
-            nx = __ddiv_rn(nx, len); ny = __ddiv_rn(ny, len); nz = __ddiv_rn(nz, len);
-            const double dd = __dmul_rn(-1.0, __dadd_rn(__dadd_rn(__dmul_rn(nx, mx), __dmul_rn(ny, my)), __dmul_rn(nz, mz)));
-            if (isfinite(nx) && isfinite(ny) && isfinite(nz) && isfinite(dd)) {
-                s_best[0] = static_cast<float>(nx); s_best[1] = static_cast<float>(ny);
-                s_best[2] = static_cast<float>(nz); s_best[3] = static_cast<float>(dd);
-            }
-        }
-        __syncthreads();
-        a = s_best[0]; b = s_best[1]; c = s_best[2]; d = s_best[3];
-    }
-    if (threadIdx.x == 0) {                                // kg_apply classifies the band points with it
+    if (threadIdx.x == 0) {                                // the best sample's plane; kg_refit_* refines it
         CmGroundPlaneDev& o = planes[zone];
-        o.plane[0] = a; o.plane[1] = b; o.plane[2] = c; o.plane[3] = d;
+        o.plane[0] = s_best[0]; o.plane[1] = s_best[1]; o.plane[2] = s_best[2]; o.plane[3] = s_best[3];
         o.iterations = s_iter; o.found = 1;
         (void)best_j;
+    }
+}
+
+// optimizeModelCoefficients, part 1: sums over the inliers of the best sample's plane, one workgroup per chunk
+// of CM_GROUND_CHUNK band points of a slab, in the order oracle/cm_oracle.h fixes (element i of the chunk ->
+// partial i mod 256, partials added pairwise). Workgroup b finds its (slab, chunk) from the slab offsets.
+__device__ __forceinline__ bool chunk_of_block(const uint32_t* __restrict__ zone_off, uint32_t blk, uint32_t* zone,
+                                               uint32_t* lo, uint32_t* hi) {
+    uint32_t first = 0;
+    for (uint32_t z = 0; z < CM_DEV_MAX_SENSORS * CM_DEV_MAX_ZONES; ++z) {
+        const uint32_t z0 = zone_off[z], z1 = zone_off[z + 1];
+        const uint32_t nch = (z1 - z0 + CM_GROUND_CHUNK - 1) / CM_GROUND_CHUNK;
+        if (blk < first + nch) {
+            *zone = z;
+            *lo = z0 + (blk - first) * CM_GROUND_CHUNK;
+            *hi = min(z1, *lo + CM_GROUND_CHUNK);
+            return true;
+        }
+        first += nch;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(256) void kg_refit_part(const CmGroundDev* __restrict__ gd, const CmFrameState* __restrict__ st,
+                                                     const float4* __restrict__ band_pts, const uint32_t* __restrict__ zone_off,
+                                                     const CmGroundPlaneDev* __restrict__ planes, double* __restrict__ chunk_sums) {
+    __shared__ double s_part[256][10];
+    __shared__ uint32_t s_zone, s_lo, s_hi, s_ok;
+    if (st->status != CM_DEV_OK || !gd->optimize) return;
+    if (threadIdx.x == 0) {
+        uint32_t z = 0, lo = 0, hi = 0;
+        s_ok = chunk_of_block(zone_off, blockIdx.x, &z, &lo, &hi) ? 1u : 0u;
+        s_zone = z; s_lo = lo; s_hi = hi;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    const CmGroundPlaneDev& pl = planes[s_zone];
+    if (!pl.found) return;
+    const float a = pl.plane[0], b = pl.plane[1], c = pl.plane[2], d = pl.plane[3], thr = gd->threshold;
+    const uint32_t lo = s_lo, hi = s_hi;
+    double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t i4 = lo + threadIdx.x; i4 < hi; i4 += 1024) {       // four loads in flight; order inside a partial kept
+        float4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = (i4 + u * 256 < hi) ? band_pts[i4 + u * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 p = q[u];
+            if (i4 + u * 256 < hi && plane_inlier(a, b, c, d, p, thr)) {
+                const double x = p.x, y = p.y, z = p.z;
+                acc[0] = __dadd_rn(acc[0], x); acc[1] = __dadd_rn(acc[1], y); acc[2] = __dadd_rn(acc[2], z);
+                acc[3] = __dadd_rn(acc[3], __dmul_rn(x, x)); acc[4] = __dadd_rn(acc[4], __dmul_rn(x, y));
+                acc[5] = __dadd_rn(acc[5], __dmul_rn(x, z)); acc[6] = __dadd_rn(acc[6], __dmul_rn(y, y));
+                acc[7] = __dadd_rn(acc[7], __dmul_rn(y, z)); acc[8] = __dadd_rn(acc[8], __dmul_rn(z, z));
+                acc[9] = __dadd_rn(acc[9], 1.0);
+            }
+        }
+    }
+    for (int k = 0; k < 10; ++k) s_part[threadIdx.x][k] = acc[k];
+    __syncthreads();
+    for (int stride = 128; stride > 0; stride >>= 1) {
+        if (static_cast<int>(threadIdx.x) < stride)
+            for (int k = 0; k < 10; ++k) s_part[threadIdx.x][k] = __dadd_rn(s_part[threadIdx.x][k], s_part[threadIdx.x + stride][k]);
+        __syncthreads();
+    }
+    if (threadIdx.x < 10) chunk_sums[static_cast<size_t>(blockIdx.x) * 10 + threadIdx.x] = s_part[0][threadIdx.x];
+}
+
+// part 2, one thread per slab: chunk sums added in chunk order, covariance, smallest eigenvector (Jacobi).
+__global__ __launch_bounds__(128) void kg_refit_final(const CmGroundDev* __restrict__ gd, const CmFrameState* __restrict__ st,
+                                                      const uint32_t* __restrict__ zone_off, const double* __restrict__ chunk_sums,
+                                                      CmGroundPlaneDev* __restrict__ planes) {
+    if (st->status != CM_DEV_OK || !gd->optimize) return;
+    const uint32_t zone = threadIdx.x;
+    if (zone >= CM_DEV_MAX_SENSORS * CM_DEV_MAX_ZONES || !planes[zone].found) return;
+    uint32_t first = 0;
+    for (uint32_t z = 0; z < zone; ++z) first += (zone_off[z + 1] - zone_off[z] + CM_GROUND_CHUNK - 1) / CM_GROUND_CHUNK;
+    const uint32_t nch = (zone_off[zone + 1] - zone_off[zone] + CM_GROUND_CHUNK - 1) / CM_GROUND_CHUNK;
+    double S[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t q = 0; q < nch; ++q)
+        for (int k = 0; k < 10; ++k) S[k] = __dadd_rn(S[k], chunk_sums[static_cast<size_t>(first + q) * 10 + k]);
+    if (!(S[9] > 3.0)) return;
+    const double cnt = S[9];
+    const double mx = __ddiv_rn(S[0], cnt), my = __ddiv_rn(S[1], cnt), mz = __ddiv_rn(S[2], cnt);
+    double A[3][3], V[3][3];
+    A[0][0] = __dsub_rn(__ddiv_rn(S[3], cnt), __dmul_rn(mx, mx)); A[0][1] = __dsub_rn(__ddiv_rn(S[4], cnt), __dmul_rn(mx, my));
+    A[0][2] = __dsub_rn(__ddiv_rn(S[5], cnt), __dmul_rn(mx, mz)); A[1][1] = __dsub_rn(__ddiv_rn(S[6], cnt), __dmul_rn(my, my));
+    A[1][2] = __dsub_rn(__ddiv_rn(S[7], cnt), __dmul_rn(my, mz)); A[2][2] = __dsub_rn(__ddiv_rn(S[8], cnt), __dmul_rn(mz, mz));
+    A[1][0] = A[0][1]; A[2][0] = A[0][2]; A[2][1] = A[1][2];
+    jacobi3(A, V);
+    int m = 0;
+    if (A[1][1] < A[m][m]) m = 1;
+    if (A[2][2] < A[m][m]) m = 2;
+    double nx = V[0][m], ny = V[1][m], nz = V[2][m];
+    const double len = __dsqrt_rn(__dadd_rn(__dadd_rn(__dmul_rn(nx, nx), __dmul_rn(ny, ny)), __dmul_rn(nz, nz)));
+    nx = __ddiv_rn(nx, len); ny = __ddiv_rn(ny, len); nz = __ddiv_rn(nz, len);
+    const double dd = __dmul_rn(-1.0, __dadd_rn(__dadd_rn(__dmul_rn(nx, mx), __dmul_rn(ny, my)), __dmul_rn(nz, mz)));
+    if (isfinite(nx) && isfinite(ny) && isfinite(nz) && isfinite(dd)) {
+        planes[zone].plane[0] = static_cast<float>(nx); planes[zone].plane[1] = static_cast<float>(ny);
+        planes[zone].plane[2] = static_cast<float>(nz); planes[zone].plane[3] = static_cast<float>(dd);
     }
 }
 
@@ -460,31 +506,40 @@ __global__ __launch_bounds__(CM_BLOCK) void kg_score0(const CmGroundDev* __restr
     }
 }
 
-// Every band point against its slab's plane: inliers are ground, the rest of the band is kept.
+// Every band point against its slab's plane: inliers are ground, the rest of the band is kept. A workgroup
+// takes 1024 consecutive band points; the inlier count of the slab its first point belongs to is collected in
+// LDS (one global add per workgroup), points of further slabs in the same chunk add on their own.
 __global__ __launch_bounds__(CM_BLOCK) void kg_apply(const CmGroundDev* __restrict__ gd, const CmFrameState* __restrict__ st,
                                                      const float4* __restrict__ band_pts, const uint32_t* __restrict__ keys_sorted,
                                                      CmGroundPlaneDev* __restrict__ planes,
                                                      unsigned char* __restrict__ keep_mask, unsigned char* __restrict__ ground_mask) {
+    __shared__ uint32_t s_cnt;
     if (st->status != CM_DEV_OK) return;
     const uint32_t n = st->n_valid;
+    const uint32_t base = blockIdx.x * 1024u;
+    if (base >= n) return;
     const float thr = gd->threshold;
-    for (uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x; i < n; i += gridDim.x * CM_BLOCK) {
-        const float4 p = band_pts[i];
-        const uint32_t zone = keys_sorted[i];
-        const CmGroundPlaneDev& pl = planes[zone];
-        const bool in = pl.found && plane_inlier(pl.plane[0], pl.plane[1], pl.plane[2], pl.plane[3], p, thr);
-        const uint32_t slot = __float_as_uint(p.w);
-        if (in) ground_mask[slot] = 1; else keep_mask[slot] = 1;
-        // inlier count of the slab: one add per wave where the whole wave sits in one slab (almost always)
-        const uint32_t z_lead = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(zone)));
-        const unsigned long long active = __ballot(true);
-        if (__ballot(zone == z_lead) == active) {
-            const uint32_t c = static_cast<uint32_t>(__popcll(__ballot(in)));
-            if (c && (threadIdx.x & 63) == static_cast<uint32_t>(__builtin_ctzll(active))) atomicAdd(&planes[zone].inliers, c);
-        } else if (in) {
-            atomicAdd(&planes[zone].inliers, 1u);
+    const uint32_t z_lead = keys_sorted[base];
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t i = base + u * 256 + threadIdx.x;
+        if (i < n) {
+            const float4 p = band_pts[i];
+            const uint32_t zone = keys_sorted[i];
+            const CmGroundPlaneDev& pl = planes[zone];
+            const bool in = pl.found && plane_inlier(pl.plane[0], pl.plane[1], pl.plane[2], pl.plane[3], p, thr);
+            const uint32_t slot = __float_as_uint(p.w);
+            if (in) ground_mask[slot] = 1; else keep_mask[slot] = 1;
+            if (in) { if (zone == z_lead) ++mine; else atomicAdd(&planes[zone].inliers, 1u); }
         }
     }
+    mine = wave_sum_u32(mine);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) atomicAdd(&planes[z_lead].inliers, s_cnt);
 }
 
 }  // namespace
@@ -500,8 +555,8 @@ void cmkg_classify(hipStream_t s, const CmFrameDev* fd, const CmGroundDev* gd, C
 }
 void cmkg_planes(hipStream_t s, const CmFrameDev* fd, const CmGroundDev* gd, const CmFrameState* st,
                  const uint32_t* keys_sorted, const uint32_t* vals_sorted, void* band_pts, uint32_t* zone_off,
-                 void* hyp0, uint32_t* valid0, uint32_t* counts0, CmGroundPlaneDev* planes, unsigned char* keep_mask,
-                 unsigned char* ground_mask, uint32_t n_padded) {
+                 void* hyp0, uint32_t* valid0, uint32_t* counts0, double* chunk_sums, CmGroundPlaneDev* planes,
+                 unsigned char* keep_mask, unsigned char* ground_mask, uint32_t n_padded) {
     const uint32_t blocks = (n_padded + CM_BLOCK * 4 - 1) / (CM_BLOCK * 4);
     const uint32_t zones = CM_DEV_MAX_SENSORS * CM_DEV_MAX_ZONES;
     float4* bp = reinterpret_cast<float4*>(band_pts);
@@ -510,5 +565,7 @@ void cmkg_planes(hipStream_t s, const CmFrameDev* fd, const CmGroundDev* gd, con
     hipLaunchKernelGGL(kg_hyp0, dim3(zones), dim3(64), 0, s, gd, st, bp, zone_off, h0, valid0, counts0);
     hipLaunchKernelGGL(kg_score0, dim3(blocks), dim3(CM_BLOCK), 0, s, gd, st, bp, keys_sorted, h0, counts0);
     hipLaunchKernelGGL(kg_ransac, dim3(zones), dim3(256), 0, s, gd, st, bp, zone_off, h0, valid0, counts0, planes);
+    hipLaunchKernelGGL(kg_refit_part, dim3(n_padded / CM_GROUND_CHUNK + zones), dim3(256), 0, s, gd, st, bp, zone_off, planes, chunk_sums);
+    hipLaunchKernelGGL(kg_refit_final, dim3(1), dim3(128), 0, s, gd, st, zone_off, chunk_sums, planes);
     hipLaunchKernelGGL(kg_apply, dim3(blocks), dim3(CM_BLOCK), 0, s, gd, st, bp, keys_sorted, planes, keep_mask, ground_mask);
 }

@@ -483,19 +483,29 @@ extern "C" void orc_ransac_plane(const orc_point* pts, size_t n, uint32_t max_it
     float pl[4];
     std::memcpy(pl, best_pl, sizeof pl);
     if (optimize && best > 3) {
-        double part[256][10];
-        std::memset(part, 0, sizeof part);
-        for (size_t i = 0; i < n; ++i) {
-            if (!plane_inlier(pl, pts[i], threshold)) continue;
-            double* a = part[i & 255];
-            const double x = pts[i].x, y = pts[i].y, z = pts[i].z;
-            a[0] += x; a[1] += y; a[2] += z;
-            a[3] += x * x; a[4] += x * y; a[5] += x * z; a[6] += y * y; a[7] += y * z; a[8] += z * z;
-            a[9] += 1.0;
+        // sums over the inliers in the fixed order of the header: chunks of 8192 points; inside a chunk element i
+        // goes to partial i mod 256 (in order), the partials are added pairwise (128, 64, ... 1); the chunk sums
+        // are added one after the other
+        double total[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t c0 = 0; c0 < n; c0 += 8192) {
+            double part[256][10];
+            std::memset(part, 0, sizeof part);
+            const size_t c1 = std::min(n, c0 + 8192);
+            for (size_t i = c0; i < c1; ++i) {
+                if (!plane_inlier(pl, pts[i], threshold)) continue;
+                double* a = part[(i - c0) & 255];
+                const double x = pts[i].x, y = pts[i].y, z = pts[i].z;
+                a[0] += x; a[1] += y; a[2] += z;
+                a[3] += x * x; a[4] += x * y; a[5] += x * z; a[6] += y * y; a[7] += y * z; a[8] += z * z;
+                a[9] += 1.0;
+            }
+            for (int stride = 128; stride > 0; stride >>= 1)
+                for (int t = 0; t < stride; ++t)
+                    for (int k = 0; k < 10; ++k) part[t][k] += part[t + stride][k];
+            for (int k = 0; k < 10; ++k) total[k] += part[0][k];
         }
-        for (int stride = 128; stride > 0; stride >>= 1)
-            for (int t = 0; t < stride; ++t)
-                for (int k = 0; k < 10; ++k) part[t][k] += part[t + stride][k];
+        double part[1][10];
+        for (int k = 0; k < 10; ++k) part[0][k] = total[k];
         const double* S = part[0];
         const double cnt = S[9];
         const double mx = S[0] / cnt, my = S[1] / cnt, mz = S[2] / cnt;

@@ -129,8 +129,9 @@ size_t orc_radius_outlier_removal(const orc_point* in, size_t n, float radius, u
  *     number on every machine;
  *   - plane of a sample and point-to-plane distance in fp32, PCL's operation order; inlier: |d| < threshold;
  *   - optimizeModelCoefficients (more than 3 inliers): mean and covariance of the inliers, plane normal =
- *     eigenvector of the smallest eigenvalue, d = -n . mean; sums in fp64 in a fixed blocked order (element i
- *     goes to partial i mod 256, the partials are added pairwise: 128, 64, ... 1) and a fixed-sweep Jacobi
+ *     eigenvector of the smallest eigenvalue, d = -n . mean; sums in fp64 in a fixed blocked order (chunks of 8192
+ *     points; in a chunk element i goes to partial i mod 256, the partials are added pairwise: 128, 64, ... 1; the
+ *     chunk sums are added one after the other) and a fixed-sweep Jacobi
  *     iteration instead of PCL's fp32 running sums and closed-form eigen33, then the inliers are selected again.
  * found = 0 (fewer than 3 points or no valid sample): no plane, no inliers, like PCL's "could not estimate". */
 typedef struct orc_plane_result {
