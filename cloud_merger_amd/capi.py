@@ -78,12 +78,13 @@ class GroundPlane(C.Structure):
 
 
 def make_ground_params(zones_per_sensor, max_iterations=1000, distance_threshold=0.3, probability=0.99,
-                       optimize=True, z_keep_max=3.0, seed=12345):
+                       optimize=True, z_keep_max=3.0, seed=12345, outlier_radius=0.0, outlier_min_neighbors=1):
     """zones_per_sensor: list (one entry per sensor) of lists of (x_min, x_length, z_max_ground); a negative
     z_max_ground keeps the slab whole. Defaults: the reference's Parameter.h:35-42."""
     g = GroundParams()
     g.max_iterations, g.distance_threshold, g.probability = max_iterations, distance_threshold, probability
     g.optimize_coefficients, g.z_keep_max, g.seed = int(optimize), z_keep_max, seed
+    g.outlier_radius, g.outlier_min_neighbors = outlier_radius, outlier_min_neighbors
     for s, zs in enumerate(zones_per_sensor):
         g.n_zones[s] = len(zs)
         for k, (x0, ln, zm) in enumerate(zs):

@@ -102,6 +102,10 @@ struct cm_ctx {
     uint32_t *valid0 = nullptr, *counts0 = nullptr;
     double* chunk_sums = nullptr;        // least-squares sums per chunk of band points
     bool frame_had_ground = false;
+    float ground_outlier_radius = 0.f;   // > 0: radius filter on every slab's band points that are not ground (:119)
+    uint32_t ground_outlier_min_nb = 0;
+    unsigned char* bmask = nullptr;      // those points (input of that filter)
+    unsigned char* zcode = nullptr;      // slab of every band point
 
     // bucket path (cm_kernels_v2.hip)
     int path_mode = 0;                   // CM_PATH: 0 auto (bucket path when it applies), 1 classic only, 2 bucket only where it applies
@@ -219,7 +223,7 @@ void free_all(cm_ctx* c) {
     F(c->keys_a); F(c->keys_b); F(c->vals_a); F(c->vals_b); F(c->hist); F(c->totals);
     F(c->seg_counts); F(c->seg_tile_counts); F(c->seg_groups); F(c->grp); F(c->partials); F(c->out_key); F(c->out_cnt); F(c->merged_total); F(c->out); F(c->merged); F(c->partial); F(c->table_entries); F(c->mask); F(c->sorted_pts); F(c->rows); F(c->d_state_o);
     F(c->rec_a); F(c->rec_b); F(c->dig); F(c->tile_state); F(c->records);
-    F(c->d_ground); F(c->d_state_g); F(c->gmask); F(c->zone_off); F(c->d_planes); F(c->hyp0); F(c->valid0); F(c->counts0); F(c->chunk_sums);
+    F(c->d_ground); F(c->d_state_g); F(c->gmask); F(c->zone_off); F(c->d_planes); F(c->hyp0); F(c->valid0); F(c->counts0); F(c->chunk_sums); F(c->bmask); F(c->zcode);
     F(c->d_frame); F(c->d_state[0]); F(c->d_state[1]);
     if (c->h_state) (void)hipHostFree(c->h_state);
     for (auto& s : c->slots) {
@@ -461,14 +465,18 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
     if (outl && mode != 0) return fail(c, CM_BAD_ARG, "outlier removal needs the whole fused cloud on one GPU (not with partial tables)");
     if (c->ground_on && (outl || mode != 0)) return fail(c, CM_BAD_ARG, "ground removal is not combined with outlier_enable or partial tables");
     if (outl && (!(p->outlier_radius > 0.0f) || !std::isfinite(p->outlier_radius))) return fail(c, CM_BAD_ARG, "outlier_radius must be > 0");
-    if (outl) for (int a = 0; a < 3; ++a) inv_cell[a] = 1.0f / (p->outlier_radius * 1.01f);   // candidate grid a little wider than r
+    const bool outl_g = c->ground_on && c->ground_outlier_radius > 0.0f;      // the ground stage's own radius filter
+    const bool any_outl = outl || outl_g;
+    const float o_radius = outl ? p->outlier_radius : c->ground_outlier_radius;
+    const uint32_t o_min_nb = outl ? p->outlier_min_neighbors : c->ground_outlier_min_nb;
+    if (any_outl) for (int a = 0; a < 3; ++a) inv_cell[a] = 1.0f / (o_radius * 1.01f);   // candidate grid a little wider than r
     uint32_t key_bits = 0, kb_o = 0;
     int grid_mode = 0;                               // 0: data min/max (k_minmax), 1: crop box, 2: bounds handed in
     if (p->crop_enable && box_grid(p->crop_min, p->crop_max, inv_leaf, &key_bits)) grid_mode = 1;
     else if (mode == 1 && bounds && box_grid(bounds, bounds + 3, inv_leaf, &key_bits)) grid_mode = 2;
     else if (mode == 1) return fail(c, CM_BAD_ARG, "partial table needs the crop box or the fused cloud's bounds to fix the grid");
     int gm_o = 0;                                    // grid of the outlier stage: crop box or data min/max
-    if (outl && p->crop_enable) {
+    if (any_outl && p->crop_enable) {
         if (!box_grid(p->crop_min, p->crop_max, inv_cell, &kb_o))
             return fail(c, CM_CAPACITY, "outlier radius too small for the crop box (radius grid exceeds 32 bits)");
         gm_o = 1;
@@ -481,10 +489,10 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
     if (mode == 1 && bounds) {
         for (int a = 0; a < 3; ++a) { f.ext_min[a] = bounds[a]; f.ext_max[a] = bounds[3 + a]; }
     }
-    if (outl) {
+    if (any_outl) {
         for (int a = 0; a < 3; ++a) f.inv_cell[a] = inv_cell[a];
-        f.outlier_r2 = static_cast<float>(static_cast<double>(p->outlier_radius) * static_cast<double>(p->outlier_radius));
-        f.outlier_min_nb = p->outlier_min_neighbors;
+        f.outlier_r2 = static_cast<float>(static_cast<double>(o_radius) * static_cast<double>(o_radius));
+        f.outlier_min_nb = o_min_nb;
     }
     c->have_result = false;
     c->out_is_merged = false;
@@ -595,6 +603,22 @@ int launch_classic(cm_ctx* c, const cm_params* p, int mode, int grid_mode, uint3
         }
     };
 
+    // Radius outlier filter over the points `in` marks (nullptr: every valid point), neighbours counted inside a
+    // point's class only when `cls` is given; survivors are marked in `out`.
+    auto radius_filter = [&](const unsigned char* in, const unsigned char* cls, unsigned char* out) -> int {
+        if (!c->sorted_pts) HIP_TRY(c, hipMalloc(&c->sorted_pts, static_cast<size_t>(c->cap_padded) * 16));
+        if (!c->rows) HIP_TRY(c, hipMalloc(&c->rows, static_cast<size_t>(CM_ROW_TABLE_CAP) * 8));
+        if (!c->d_state_o) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_state_o), sizeof(CmFrameState)));
+        const uint32_t passes_o = gm_o ? (kb_o + CM_RADIX_BITS - 1) / CM_RADIX_BITS : CM_MAX_PASSES;
+        HIP_TRY(c, hipMemsetAsync(c->d_state_o, 0, sizeof(CmFrameState), st));
+        if (!gm_o) { prof_mark(c, "k_minmax"); cmk_minmax(st, c->d_frame, c->partials, n_partials, in); }
+        keys_and_sort(c->d_state_o, gm_o, 1, in, nullptr, passes_o);
+        prof_mark(c, "outlier_mask");
+        cmk_outlier_mask(st, c->d_frame, c->d_state_o, c->keys_a, c->vals_a, c->keys_b, c->vals_b, c->sorted_pts,
+                         c->rows, out, f.n_padded, cls);
+        return CM_OK;
+    };
+    const bool ground_outl = c->ground_on && mode == 0 && c->ground_outlier_radius > 0.0f;
     c->frame_mask = nullptr;
     c->frame_had_ground = false;
     if (c->ground_on && mode == 0) {
@@ -614,6 +638,12 @@ int launch_classic(cm_ctx* c, const cm_params* p, int mode, int grid_mode, uint3
             if (!c->counts0) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->counts0), nh * 4));
             if (!c->chunk_sums) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->chunk_sums), (static_cast<size_t>(c->cap_padded) / CM_GROUND_CHUNK + CM_DEV_MAX_SENSORS * CM_DEV_MAX_ZONES + 1) * 10 * sizeof(double)));
         }
+        if (ground_outl) {
+            if (!c->bmask) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->bmask), c->cap_padded));
+            if (!c->zcode) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->zcode), c->cap_padded));
+            HIP_TRY(c, hipMemsetAsync(c->bmask, 0, f.n_padded, st));
+            HIP_TRY(c, hipMemsetAsync(c->zcode, 0xFF, f.n_padded, st));
+        }
         if (!c->ground_uploaded) { cmkg_setup(st, c->ground, c->d_ground); c->ground_uploaded = true; }
         HIP_TRY(c, hipMemsetAsync(c->d_state_g, 0, sizeof(CmFrameState), st));
         HIP_TRY(c, hipMemsetAsync(c->mask, 0, f.n_padded, st));
@@ -623,35 +653,33 @@ int launch_classic(cm_ctx* c, const cm_params* p, int mode, int grid_mode, uint3
         ++c->frame_seq;
         prof_mark(c, "kg_classify");
         cmkg_classify(st, c->d_frame, c->d_ground, c->d_state_g, c->keys_a, c->hist, grp0, grp0_next, c->grp + 2 * gstride,
-                      gw, static_cast<uint32_t>(gstride), c->mask, nt);
+                      gw, static_cast<uint32_t>(gstride), c->mask, ground_outl ? c->zcode : nullptr, nt);
         if (big) { prof_mark(c, "k_gscan"); cmk_gscan(st, c->d_state_g, grp0, c->totals, 0, n_groups); }
         prof_mark(c, "k_scatter(slabs)");
         cmk_scatter(st, c->d_state_g, c->keys_a, c->vals_a, c->keys_b, c->vals_b, c->hist, grp0, big ? c->totals : nullptr, 0, nt,
                     n_groups, f.n_padded, c->lds_rank);
         prof_mark(c, "kg_ransac");
         cmkg_planes(st, c->d_frame, c->d_ground, c->d_state_g, c->keys_b, c->vals_b, c->sorted_pts, c->zone_off, c->hyp0,
-                    c->valid0, c->counts0, c->chunk_sums, c->d_planes, c->mask, c->gmask, f.n_padded);
+                    c->valid0, c->counts0, c->chunk_sums, c->d_planes, ground_outl ? c->bmask : c->mask, c->gmask, f.n_padded);
+        if (ground_outl) {
+            // removeGround's outlierRemoval(no_ground_cloud_ptr) (:119): among the band points of a slab that are
+            // not ground, those with no neighbour within the radius go; survivors join the keep-mask
+            const int e = radius_filter(c->bmask, c->zcode, c->mask);
+            if (e != CM_OK) return e;
+        }
         c->frame_mask = c->mask;
         c->frame_had_ground = true;
     }
     if (outl) {
         // Radius outlier removal first: it decides which points the voxel grid sees at all.
         if (!c->mask) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->mask), c->cap_padded));
-        if (!c->sorted_pts) HIP_TRY(c, hipMalloc(&c->sorted_pts, static_cast<size_t>(c->cap_padded) * 16));
-        if (!c->rows) HIP_TRY(c, hipMalloc(&c->rows, static_cast<size_t>(CM_ROW_TABLE_CAP) * 8));
-        if (!c->d_state_o) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_state_o), sizeof(CmFrameState)));
-        const uint32_t passes_o = gm_o ? (kb_o + CM_RADIX_BITS - 1) / CM_RADIX_BITS : CM_MAX_PASSES;
-        HIP_TRY(c, hipMemsetAsync(c->d_state_o, 0, sizeof(CmFrameState), st));
         HIP_TRY(c, hipMemsetAsync(c->mask, 0, f.n_padded, st));
-        if (!gm_o) { prof_mark(c, "k_minmax"); cmk_minmax(st, c->d_frame, c->partials, n_partials, nullptr); }
-        keys_and_sort(c->d_state_o, gm_o, 1, nullptr, nullptr, passes_o);
-        prof_mark(c, "outlier_mask");
-        cmk_outlier_mask(st, c->d_frame, c->d_state_o, c->keys_a, c->vals_a, c->keys_b, c->vals_b, c->sorted_pts,
-                         c->rows, c->mask, f.n_padded);
+        const int e = radius_filter(nullptr, nullptr, c->mask);
+        if (e != CM_OK) return e;
         c->frame_mask = c->mask;
     }
     if (!c->from_crop) { prof_mark(c, "k_minmax"); cmk_minmax(st, c->d_frame, c->partials, n_partials, c->frame_mask); }
-    keys_and_sort(state, grid_mode, 0, c->frame_mask, outl ? c->d_state_o : nullptr, passes);
+    keys_and_sort(state, grid_mode, 0, c->frame_mask, (outl || ground_outl) ? c->d_state_o : nullptr, passes);
     prof_mark(c, "k_seg_count");
     uint32_t* seg_groups = nseg > CM_SEG_DIRECT_TILES ? c->seg_groups : nullptr;
     cmk_seg_count(st, state, c->keys_a, c->keys_b, c->seg_tile_counts, seg_groups, mode == 1 ? 1u : f.min_pts, nseg);
@@ -1086,7 +1114,7 @@ int cm_set_ground_removal(cm_ctx* c, const cm_ground_params* g) {
     if (g->max_iterations < 1 || g->max_iterations > 100000) return fail(c, CM_BAD_ARG, "max_iterations must be in 1..100000");
     if (!(g->distance_threshold > 0.0f) || !std::isfinite(g->distance_threshold)) return fail(c, CM_BAD_ARG, "distance_threshold must be > 0");
     if (!(g->probability > 0.0f && g->probability < 1.0f)) return fail(c, CM_BAD_ARG, "probability must be in (0, 1)");
-    if (g->outlier_radius != 0.0f) return fail(c, CM_BAD_ARG, "per-band outlier removal is not available in this version (outlier_radius must be 0)");
+    if (g->outlier_radius < 0.0f || !std::isfinite(g->outlier_radius)) return fail(c, CM_BAD_ARG, "outlier_radius must be >= 0");
     CmGroundDev d;
     std::memset(&d, 0, sizeof d);
     for (uint32_t s = 0; s < CM_MAX_SENSORS; ++s) {
@@ -1109,6 +1137,8 @@ int cm_set_ground_removal(cm_ctx* c, const cm_ground_params* g) {
     d.optimize = g->optimize_coefficients ? 1u : 0u;
     d.seed = g->seed;
     c->ground = d;
+    c->ground_outlier_radius = g->outlier_radius;
+    c->ground_outlier_min_nb = g->outlier_min_neighbors;
     c->ground_uploaded = false;
     c->ground_on = true;
     return CM_OK;

@@ -15,7 +15,7 @@ void cmk_keys(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* k
 // Outlier stage after the sort by the radius grid: gather into sorted order, row table, neighbour counts -> mask.
 void cmk_outlier_mask(hipStream_t s, const CmFrameDev* fd, const CmFrameState* st, const uint32_t* keys_a,
                       const uint32_t* vals_a, const uint32_t* keys_b, const uint32_t* vals_b, void* sorted_pts,
-                      void* rows, unsigned char* mask, uint32_t n_padded);
+                      void* rows, unsigned char* mask, uint32_t n_padded, const unsigned char* cls = nullptr);
 void cmk_hist(hipStream_t s, const CmFrameState* st, const uint32_t* keys, uint32_t* hist, uint32_t* grp,
               uint32_t pass, uint32_t n_tiles);
 void cmk_gscan(hipStream_t s, const CmFrameState* st, uint32_t* grp, uint32_t* totals, uint32_t pass,
@@ -61,7 +61,8 @@ void cmk2_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameSt
 void cmkg_setup(hipStream_t s, const CmGroundDev& g, CmGroundDev* d_ground);
 void cmkg_classify(hipStream_t s, const CmFrameDev* fd, const CmGroundDev* gd, CmFrameState* st, uint32_t* keys,
                    uint32_t* hist, uint32_t* grp_acc, uint32_t* grp_clear_a, uint32_t* grp_clear_b,
-                   uint32_t n_group_words, uint32_t n_clear_a_words, unsigned char* keep_mask, uint32_t n_tiles);
+                   uint32_t n_group_words, uint32_t n_clear_a_words, unsigned char* keep_mask, unsigned char* zcode,
+                   uint32_t n_tiles);
 // slab offsets + band points in slab order, then one RANSAC workgroup per slab -> keep / ground masks
 void cmkg_planes(hipStream_t s, const CmFrameDev* fd, const CmGroundDev* gd, const CmFrameState* st,
                  const uint32_t* keys_sorted, const uint32_t* vals_sorted, void* band_pts, uint32_t* zone_off,

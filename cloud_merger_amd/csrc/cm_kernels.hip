@@ -967,7 +967,8 @@ __global__ __launch_bounds__(CM_BLOCK) void k_neighbors(const CmFrameDev* __rest
                                                         const uint32_t* __restrict__ keys_b,
                                                         const float4* __restrict__ sorted_pts,
                                                         const uint2* __restrict__ rows,
-                                                        unsigned char* __restrict__ mask) {
+                                                        unsigned char* __restrict__ mask,
+                                                        const unsigned char* __restrict__ cls) {
     if (st->status != CM_DEV_OK) return;
     const uint32_t n = st->n_valid;
     const uint32_t dx = static_cast<uint32_t>(st->div_b[0]), dy = static_cast<uint32_t>(st->div_b[1]),
@@ -983,9 +984,13 @@ __global__ __launch_bounds__(CM_BLOCK) void k_neighbors(const CmFrameDev* __rest
         const float4 me = sorted_pts[p];
         const uint32_t jk = key / dx, i = key - jk * dx, k = jk / dy, j = jk - k * dy;
         uint32_t cnt = 1;                                         // the point itself (distance 0)
+        // cls: neighbours count only inside the point's own class (the ground stage filters every slab's
+        // band on its own, like the reference's per-slab outlierRemoval call)
+        const uint32_t my_cls = cls ? cls[__float_as_uint(me.w)] : 0u;
         auto test = [&](const float4& pt) {
             const float ex = __fsub_rn(me.x, pt.x), ey = __fsub_rn(me.y, pt.y), ez = __fsub_rn(me.z, pt.z);
-            return __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez)) < r2;
+            const bool near = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez)) < r2;
+            return near && (!cls || cls[__float_as_uint(pt.w)] == my_cls);
         };
         // Own row first, outward from the point's own sorted position: the points of its own cell
         // are its immediate neighbours in the sorted order (no search, early exit for most points).
@@ -1170,13 +1175,13 @@ void cmk_keys(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* k
 }
 void cmk_outlier_mask(hipStream_t s, const CmFrameDev* fd, const CmFrameState* st, const uint32_t* keys_a,
                       const uint32_t* vals_a, const uint32_t* keys_b, const uint32_t* vals_b, void* sorted_pts,
-                      void* rows, unsigned char* mask, uint32_t n_padded) {
+                      void* rows, unsigned char* mask, uint32_t n_padded, const unsigned char* cls) {
     const uint32_t blocks = (n_padded + CM_BLOCK * 4 - 1) / (CM_BLOCK * 4);
     CM_LAUNCH(k_gather_sorted, blocks, CM_BLOCK, s, fd, st, vals_a, vals_b, reinterpret_cast<float4*>(sorted_pts));
     CM_LAUNCH(k_row_clear, 1024, CM_BLOCK, s, st, reinterpret_cast<uint2*>(rows));
     CM_LAUNCH(k_row_table, blocks, CM_BLOCK, s, st, keys_a, keys_b, reinterpret_cast<uint2*>(rows));
     CM_LAUNCH(k_neighbors, (n_padded + CM_BLOCK - 1) / CM_BLOCK, CM_BLOCK, s, fd, st, keys_a, keys_b,
-              reinterpret_cast<const float4*>(sorted_pts), reinterpret_cast<const uint2*>(rows), mask);
+              reinterpret_cast<const float4*>(sorted_pts), reinterpret_cast<const uint2*>(rows), mask, cls);
 }
 void cmk_hist(hipStream_t s, const CmFrameState* st, const uint32_t* keys, uint32_t* hist, uint32_t* grp,
               uint32_t pass, uint32_t n_tiles) {

@@ -43,7 +43,8 @@ __global__ __launch_bounds__(CM_BLOCK) void kg_classify(const CmFrameDev* __rest
                                                         uint32_t* __restrict__ grp_clear_a,
                                                         uint32_t* __restrict__ grp_clear_b,
                                                         uint32_t n_group_words, uint32_t n_clear_a_words,
-                                                        unsigned char* __restrict__ keep_mask) {
+                                                        unsigned char* __restrict__ keep_mask,
+                                                        unsigned char* __restrict__ zcode) {
     __shared__ uint32_t lh[CM_RADIX];
     const uint32_t tile = blockIdx.x;
     for (uint32_t k = tile * CM_BLOCK + threadIdx.x; k < 3 * n_group_words; k += gridDim.x * CM_BLOCK) grp_clear_b[k] = 0;
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(CM_BLOCK) void kg_classify(const CmFrameDev* __rest
         if (key != CM_INVALID_KEY) atomicAdd(&lh[key & (CM_RADIX - 1)], 1u);
         keys[slot0 + r * 64] = key;
         if (keep) keep_mask[slot0 + r * 64] = 1;                                      // masks are zeroed before the stage
+        if (zcode && key != CM_INVALID_KEY) zcode[slot0 + r * 64] = static_cast<unsigned char>(key);   // slab of a band point
     }
     __syncthreads();
     const uint32_t c = lh[threadIdx.x];
@@ -549,9 +551,10 @@ void cmkg_setup(hipStream_t s, const CmGroundDev& g, CmGroundDev* d_ground) {
 }
 void cmkg_classify(hipStream_t s, const CmFrameDev* fd, const CmGroundDev* gd, CmFrameState* st, uint32_t* keys,
                    uint32_t* hist, uint32_t* grp_acc, uint32_t* grp_clear_a, uint32_t* grp_clear_b,
-                   uint32_t n_group_words, uint32_t n_clear_a_words, unsigned char* keep_mask, uint32_t n_tiles) {
+                   uint32_t n_group_words, uint32_t n_clear_a_words, unsigned char* keep_mask, unsigned char* zcode,
+                   uint32_t n_tiles) {
     hipLaunchKernelGGL(kg_classify, dim3(n_tiles), dim3(CM_BLOCK), 0, s, fd, gd, st, keys, hist, grp_acc, grp_clear_a,
-                       grp_clear_b, n_group_words, n_clear_a_words, keep_mask);
+                       grp_clear_b, n_group_words, n_clear_a_words, keep_mask, zcode);
 }
 void cmkg_planes(hipStream_t s, const CmFrameDev* fd, const CmGroundDev* gd, const CmFrameState* st,
                  const uint32_t* keys_sorted, const uint32_t* vals_sorted, void* band_pts, uint32_t* zone_off,

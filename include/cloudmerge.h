@@ -210,8 +210,8 @@ CM_API int cm_merge_tables(cm_ctx* ctx, const void* const* dev_tables, const uin
  * Differences from the reference, all documented in DESIGN.md §10: RANSAC samples come from a counter-based
  * generator, not boost::mt19937 (planes agree statistically, not draw for draw); a point on the border of two
  * slabs goes to the first one only (the reference's closed intervals put it in both); points keep sensor order
- * (the reference concatenates slab by slab); the radius outlier filter that removeGround applies to the band's
- * non-ground points (:119) is applied when outlier_radius > 0, among the points of the same slab. */
+ * (the reference concatenates slab by slab). The radius outlier filter that removeGround applies to the band's
+ * non-ground points (:119) runs when outlier_radius > 0, among the points of the same slab, like there. */
 #define CM_MAX_ZONES 8
 typedef struct cm_zone {
     float x_min, x_length;         /* getCloudPart(cloud, part, length, deviation): x in [x_min, x_min + x_length] */

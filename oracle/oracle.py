@@ -153,8 +153,10 @@ def ground_split(points, zones, sensor, gp):
     and the top / Livox callbacks, pc_preprocessing_main.cpp:228-312, :436-497), composed from the pieces above:
     for every slab (x_min, x_length, z_max_ground) in order — a point on a border goes to the first slab only —
     band / above-band split (removeGround :81-91), plane on the band, inliers = ground. gp: dict with
-    max_iterations, threshold, probability, optimize, z_keep_max, seed. Returns (keep mask, ground mask, planes)
-    over `points` (no-ground = points[keep], ground = points[ground])."""
+    max_iterations, threshold, probability, optimize, z_keep_max, seed, and optionally outlier_radius /
+    outlier_min_neighbors: removeGround's outlierRemoval(no_ground_cloud_ptr) (:119) on the band points of the
+    slab that are not ground. Returns (keep mask, ground mask, planes) over `points` (no-ground = points[keep],
+    ground = points[ground])."""
     x, z = points["x"], points["z"]
     taken = np.zeros(len(points), dtype=bool)
     keep = np.zeros(len(points), dtype=bool)
@@ -176,7 +178,11 @@ def ground_split(points, zones, sensor, gp):
         res, inl = ransac_plane(points[idx], gp["max_iterations"], gp["threshold"], gp["probability"], gp["optimize"],
                                 gp["seed"], sensor * 8 + k)
         ground[idx[inl]] = True
-        keep[idx[~inl]] = True
+        rest = idx[~inl]
+        if gp.get("outlier_radius", 0) and len(rest):
+            _, ok = radius_outlier_removal(points[rest], gp["outlier_radius"], gp.get("outlier_min_neighbors", 1))
+            rest = rest[ok]
+        keep[rest] = True
         planes.append(res)
     return keep, ground, planes
 

@@ -47,7 +47,8 @@ def run(sensors, zones, params, gp, cm=None):
         cm = capi.CloudMerger(max_points_total=n_total, max_sensors=len(sensors), flags=capi.FLAG_OCCUPANCY)
     try:
         cm.set_ground_removal(capi.make_ground_params(zones, gp["max_iterations"], gp["threshold"], gp["probability"],
-                                                      gp["optimize"], gp["z_keep_max"], gp["seed"]))
+                                                      gp["optimize"], gp["z_keep_max"], gp["seed"],
+                                                      gp.get("outlier_radius", 0.0), gp.get("outlier_min_neighbors", 1)))
         cm.submit_all(sensors)
         res = cm.merge_voxelize(params)
         out = cm.result(res.n_out)
@@ -118,6 +119,26 @@ def test_four_sensors_with_poses_keep_all_slab_and_gaps():
     check(sensors, zones, params)
 
 
+def test_band_outlier_filter_per_slab():
+    """removeGround's outlierRemoval(:119): of a slab's band points that are not ground, those without a neighbour
+    within 0.15 m (in the same slab's set) go. Sparse clutter in the band makes many of them lonely; two points
+    that are close to each other but sit in different slabs do not save each other."""
+    rng = np.random.default_rng(25)
+    ground = scene(rng, 60_000, obj_frac=0.0)
+    clutter = np.stack([rng.uniform(-15, 60, 6_000), rng.uniform(-5, 5, 6_000), rng.uniform(0.45, 2.4, 6_000)], 1)
+    pair = np.array([[18.95, 0.0, 1.0], [19.05, 0.0, 1.0]])           # 10 cm apart, slab border at x = 19 between them
+    xyz = np.concatenate([ground, clutter, pair]).astype(np.float32)
+    sensors = [xyzi_cloud(xyz, rng.uniform(0, 255, len(xyz)))]
+    params = MergeParams(leaf=(0.1,) * 3, min_points_per_voxel=0, **ROI)
+    gp = dict(GP, outlier_radius=0.15, outlier_min_neighbors=1)
+    g, _ = check(sensors, [FRONT], params, gp)
+    g0, _ = check(sensors, [FRONT], params, GP)
+    assert len(g["merged"]) < len(g0["merged"]) and len(g["ground"]) == len(g0["ground"])
+    got = a4(g["merged"])
+    assert not ((np.abs(got[:, 0] - 18.95) < 1e-4) & (got[:, 2] == 1.0)).any()      # the pair: each alone in its slab
+    assert not ((np.abs(got[:, 0] - 19.05) < 1e-4) & (got[:, 2] == 1.0)).any()
+
+
 def test_degenerate_bands():
     """Empty band, two-point band (no model: nothing is ground), and a band of exactly collinear points (every
     sample is skipped: no plane either)."""
@@ -159,7 +180,7 @@ def test_argument_checks():
         with pytest.raises(capi.CloudMergeError):
             cm.set_ground_removal(g)
         g = capi.make_ground_params([FRONT])
-        g.outlier_radius = 0.15
+        g.outlier_radius = -1.0
         with pytest.raises(capi.CloudMergeError):
             cm.set_ground_removal(g)
         cm.set_ground_removal(capi.make_ground_params([FRONT]))
