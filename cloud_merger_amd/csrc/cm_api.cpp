@@ -121,6 +121,11 @@ struct cm_ctx {
     uint32_t v2_retry_after = 256;       // ... after this many, try one global pass fewer again (doubles on failure)
     uint32_t v2_off_frames = 0;          // ... or give the path a rest
     bool last_v2 = false, last_predicted = false;
+    bool post_bucket = false;            // the frame's pre-stages (ground / outlier removal) run first, then the bucket path
+    uint32_t post_g = 0, post_low = 0;
+    bool last_outl = false;
+    int last_gm_o = 0;
+    uint32_t last_kb_o = 0;
     cm_params last_params;
     int last_grid_mode = 0;
     uint32_t last_key_bits = 0;
@@ -389,7 +394,8 @@ int bootstrap_box(cm_ctx* c) {
 
 // The launch sequence of cm_kernels_v2.hip for the frame in c->frame: n_global 8-bit passes over the
 // key bits above `low_bits`, then the local finish.
-int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits) {
+int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits, const unsigned char* mask,
+                  const CmFrameState* st_outlier) {
     CmFrameDev& f = c->frame;
     hipStream_t st = c->stream;
     const size_t npad = c->cap_padded;
@@ -418,10 +424,10 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
     uint32_t* grp0_next = c->grp + gstride * ((c->frame_seq & 1u) ^ 1u);
     ++c->frame_seq;
     c->h_state->err = 0;                               // error words are written straight into the host record
-    c->frame_mask = nullptr;
+    c->frame_mask = mask;
     prof_mark(c, "k2_hist0");
     cmk2_hist0(st, c->d_frame, state, c->hist, grp0, grp0_next, c->grp + 2 * gstride, gw, static_cast<uint32_t>(gstride),
-               c->tile_state, f.n_padded / 1024 + 2, c->records, grid_mode, low_bits, n_global, nt);
+               c->tile_state, f.n_padded / 1024 + 2, c->records, grid_mode, low_bits, n_global, nt, mask, st_outlier);
     for (uint32_t pass = 0; pass < n_global; ++pass) {
         uint32_t* grp = pass == 0 ? grp0 : c->grp + 2 * gstride + static_cast<size_t>(pass - 1) * gw;
         if (pass > 0) { prof_mark(c, "k2_hist"); cmk2_hist(st, state, c->dig, c->hist, grp, nt); }
@@ -431,7 +437,7 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
         void* out = (pass & 1u) ? c->rec_b : c->rec_a;
         cmk2_scatter(st, pass == 0, c->d_frame, state, in, out, c->dig, c->hist, grp, big ? c->totals : nullptr,
                      low_bits + 8 * pass, pass + 1 < n_global ? low_bits + 8 * (pass + 1) : 32u, nt, n_groups,
-                     f.n_padded, c->records, nt, grid_mode == 2 ? 1 : 0);
+                     f.n_padded, c->records, nt, grid_mode == 2 ? 1 : 0, mask);
     }
     prof_mark(c, "k2_local");
     cmk2_local(st, c->d_frame, state, state_next, c->h_state_dev, ((n_global - 1) & 1u) ? c->rec_b : c->rec_a,
@@ -513,7 +519,12 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
 
     // Bucket path: centroids of one GPU's whole frame, with a box known before the first point is
     // read — the crop box, or the last frame's bounds plus a margin (verified on the device).
-    bool want_v2 = c->path_mode != 1 && mode == 0 && !outl && !c->ground_on && c->lds_rank;
+    // Frames with pre-stages (ground / outlier removal, which leave a keep-mask) can use it too when the crop box
+    // fixes the grid: the pre-stages run first (launch_classic), then the bucket path takes the voxel stage.
+    const bool pre = outl || c->ground_on;
+    c->post_bucket = false;
+    c->last_outl = outl; c->last_gm_o = gm_o; c->last_kb_o = kb_o;
+    bool want_v2 = c->path_mode != 1 && mode == 0 && c->lds_rank && (!pre || grid_mode == 1);
     if (want_v2 && c->v2_off_frames) { --c->v2_off_frames; want_v2 = false; }
     if (want_v2) {
         int gm = grid_mode;
@@ -543,7 +554,8 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
             if (g > 1 && 8 * (g - 1) >= kb) g = 0;           // nothing left for the local finish to add
             if (g >= 1 && g <= CM_MAX_PASSES) {
                 const uint32_t low = kb > 8 * g ? kb - 8 * g : 0;
-                return launch_bucket(c, gm, g, low);
+                if (!pre) return launch_bucket(c, gm, g, low, nullptr, nullptr);
+                c->post_bucket = true; c->post_g = g; c->post_low = low;
             }
         }
     }
@@ -678,6 +690,10 @@ int launch_classic(cm_ctx* c, const cm_params* p, int mode, int grid_mode, uint3
         if (e != CM_OK) return e;
         c->frame_mask = c->mask;
     }
+    if (c->post_bucket) {                                  // the voxel stage goes to the bucket path, with the keep-mask
+        c->post_bucket = false;
+        return launch_bucket(c, 1, c->post_g, c->post_low, c->frame_mask, (outl || ground_outl) ? c->d_state_o : nullptr);
+    }
     if (!c->from_crop) { prof_mark(c, "k_minmax"); cmk_minmax(st, c->d_frame, c->partials, n_partials, c->frame_mask); }
     keys_and_sort(state, grid_mode, 0, c->frame_mask, (outl || ground_outl) ? c->d_state_o : nullptr, passes);
     prof_mark(c, "k_seg_count");
@@ -736,9 +752,14 @@ int wait_frame(cm_ctx* c, cm_result* res) {
                     // clouds only, never a torn one) and hold them until the kernels are enqueued, as enqueue does.
                     std::vector<std::unique_lock<std::mutex>> locks;
                     const cm_params pr = c->last_params;
+                    const CmFrameDev prev = c->frame;          // what enqueue derived from the parameters stays
                     int e = build_frame(c, &pr, false, locks, false);
+                    for (int a = 0; a < 3; ++a) c->frame.inv_cell[a] = prev.inv_cell[a];
+                    c->frame.outlier_r2 = prev.outlier_r2;
+                    c->frame.outlier_min_nb = prev.outlier_min_nb;
+                    c->post_bucket = false;
                     if (e == CM_OK && c->frame.n_padded)
-                        e = launch_classic(c, &pr, 0, c->last_grid_mode, c->last_key_bits, false, 0, 0);
+                        e = launch_classic(c, &pr, 0, c->last_grid_mode, c->last_key_bits, c->last_outl, c->last_gm_o, c->last_kb_o);
                     else if (e == CM_OK)
                         e = CM_NOT_READY;
                     if (e != CM_OK) { c->pending = false; return e == CM_NOT_READY ? fail(c, CM_INTERNAL, "frame could not be redone: its clouds were cleared") : e; }

@@ -126,7 +126,9 @@ __global__ __launch_bounds__(CM2_BLOCK) void k2_hist0(const CmFrameDev* __restri
                                                       unsigned long long* __restrict__ tile_state,
                                                       uint32_t n_tile_state,
                                                       float* __restrict__ records,
-                                                      int grid_mode, uint32_t shift0, uint32_t n_global_passes) {
+                                                      int grid_mode, uint32_t shift0, uint32_t n_global_passes,
+                                                      const unsigned char* __restrict__ mask,
+                                                      const CmFrameState* __restrict__ st_outlier) {
     __shared__ uint32_t lh[CM_RADIX];
     __shared__ float s_mm[CM2_WAVES][6];
     __shared__ uint32_t s_cnt[CM2_WAVES];
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(CM2_BLOCK) void k2_hist0(const CmFrameDev* __restri
     for (uint32_t k = tile * CM2_BLOCK + threadIdx.x; k < n_tile_state; k += gridDim.x * CM2_BLOCK) tile_state[k] = 0ull;
 
     if (tile == 0 && threadIdx.x == 0) {                 // the box and its grid, as the host set them up
-        st->status = CM_DEV_OK;
+        st->status = (st_outlier && st_outlier->status == CM_DEV_OUTLIER_GRID) ? CM_DEV_OUTLIER_GRID : CM_DEV_OK;
         for (int a = 0; a < 3; ++a) {
             st->min_p[a] = grid_mode == 2 ? fd->ext_min[a] : fd->crop_min[a];
             st->max_p[a] = grid_mode == 2 ? fd->ext_max[a] : fd->crop_max[a];
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(CM2_BLOCK) void k2_hist0(const CmFrameDev* __restri
         const float x = xf_row(m[0], m[1], m[2], m[3], p[r].x, p[r].y, p[r].z);
         const float y = xf_row(m[4], m[5], m[6], m[7], p[r].x, p[r].y, p[r].z);
         const float z = xf_row(m[8], m[9], m[10], m[11], p[r].x, p[r].y, p[r].z);
-        if (point_valid(x, y, z, crop, fd->crop_min, fd->crop_max)) {
+        if (point_valid(x, y, z, crop, fd->crop_min, fd->crop_max) && (!mask || mask[slot0 + r * 64])) {
             bool in;
             const uint32_t key = key_of(b, x, y, z, &in);
             if (predicted) {                              // a crop box holds every valid point by construction
@@ -265,7 +267,8 @@ __global__ __launch_bounds__(CM2_BLOCK, 3) void k2_scatter(const CmFrameDev* __r
                                                            uint32_t shift, uint32_t next_shift,
                                                            uint32_t n_groups, uint32_t n_padded,
                                                            const float* __restrict__ records,
-                                                           uint32_t n_records, int fold) {
+                                                           uint32_t n_records, int fold,
+                                                           const unsigned char* __restrict__ mask) {
     __shared__ float4 srec[CM_TILE / 2];                // staging in two halves: 41 KB per workgroup, three per CU
     __shared__ uint32_t whist[CM2_WAVES][CM_RADIX];
     __shared__ uint32_t gofs[CM_RADIX];
@@ -301,7 +304,8 @@ __global__ __launch_bounds__(CM2_BLOCK, 3) void k2_scatter(const CmFrameDev* __r
             rec[r].w = all_fields ? p[r].i : 0.f;
             bool in = false;
             key[r] = 0;
-            if (point_valid(rec[r].x, rec[r].y, rec[r].z, crop, fd->crop_min, fd->crop_max))
+            if (point_valid(rec[r].x, rec[r].y, rec[r].z, crop, fd->crop_min, fd->crop_max) &&
+                (!mask || mask[first + r * 64]))
                 key[r] = key_of(b, rec[r].x, rec[r].y, rec[r].z, &in);
             if (in) vmask |= 1u << r;
         }
@@ -791,10 +795,11 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
 void cmk2_hist0(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* hist, uint32_t* grp_acc,
                 uint32_t* grp_clear_a, uint32_t* grp_clear_b, uint32_t n_group_words, uint32_t n_clear_a_words,
                 unsigned long long* tile_state, uint32_t n_tile_state, float* records, int grid_mode,
-                uint32_t shift0, uint32_t n_global_passes, uint32_t n_tiles) {
+                uint32_t shift0, uint32_t n_global_passes, uint32_t n_tiles, const unsigned char* mask,
+                const CmFrameState* st_outlier) {
     hipLaunchKernelGGL(k2_hist0, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, st, hist, grp_acc, grp_clear_a, grp_clear_b,
                        n_group_words, n_clear_a_words, tile_state, n_tile_state, records, grid_mode, shift0,
-                       n_global_passes);
+                       n_global_passes, mask, st_outlier);
 }
 void cmk2_hist(hipStream_t s, const CmFrameState* st, const unsigned char* dig, uint32_t* hist, uint32_t* grp,
                uint32_t n_tiles) {
@@ -803,15 +808,15 @@ void cmk2_hist(hipStream_t s, const CmFrameState* st, const unsigned char* dig, 
 void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, CmFrameState* st, const void* rec_in, void* rec_out,
                   unsigned char* dig_out, const uint32_t* hist, const uint32_t* grp, const uint32_t* totals,
                   uint32_t shift, uint32_t next_shift, uint32_t n_tiles, uint32_t n_groups, uint32_t n_padded,
-                  const float* records, uint32_t n_records, int fold) {
+                  const float* records, uint32_t n_records, int fold, const unsigned char* mask) {
     const float4* in = reinterpret_cast<const float4*>(rec_in);
     float4* o = reinterpret_cast<float4*>(rec_out);
     if (first)
         hipLaunchKernelGGL(k2_scatter<true>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, st, in, o, dig_out, hist, grp,
-                           totals, shift, next_shift, n_groups, n_padded, records, n_records, fold);
+                           totals, shift, next_shift, n_groups, n_padded, records, n_records, fold, mask);
     else
         hipLaunchKernelGGL(k2_scatter<false>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, st, in, o, dig_out, hist, grp,
-                           totals, shift, next_shift, n_groups, n_padded, records, n_records, fold);
+                           totals, shift, next_shift, n_groups, n_padded, records, n_records, fold, mask);
 }
 void cmk2_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next, uint32_t* host_state,
                 const void* rec, unsigned long long* tile_state, uint32_t* ticket, void* out, uint32_t* out_key,

@@ -409,13 +409,14 @@ def test_outlier_removal_no_crop(radius, min_nb):
     assert 0 < g["res"].n_merged < g["res"].n_in          # some points really are outliers
 
 
-def test_outlier_removal_reference_parameters():
+def test_outlier_removal_reference_parameters(sort_path):
     """The class-based reference node's chain: ROI crop, outlier removal (r from Parameter.h), VoxelGrid."""
     sensors, _ = synth.config3(n_per_sensor=200_000, n_sensors=6)
     params = MergeParams(crop_min=(-15.0, -5.0, -0.5), crop_max=(60.0, 5.0, 3.0), outlier_radius=0.15,
                          outlier_min_neighbors=1)
     g, rep = check_against_oracle(sensors, params)
     assert g["res"].bounds_from_crop == 1 and 0 < g["res"].n_merged
+    assert bool(g["res"].path_flags & BUCKET) == (sort_path == "auto")     # crop box: the voxel stage after the filter takes the bucket path
 
 
 def test_outlier_removal_small_known_case():

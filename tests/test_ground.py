@@ -97,6 +97,7 @@ def test_front_sensor_five_slabs():
         n = np.array(pl.plane[:3]) * np.sign(pl.plane[2])
         assert pl.found and abs(n[0] / n[2] + 0.01) < 2e-3 and abs(n[1] / n[2] + 0.02) < 5e-3
     assert 0 < len(g["ground"]) < 120_000 and len(g["ground"]) + len(g["merged"]) <= 120_000
+    assert g["res"].path_flags & 2          # with the ROI fixing the grid the voxel stage runs on the bucket path (CM_PATH_BUCKET)
 
 
 def test_four_sensors_with_poses_keep_all_slab_and_gaps():
@@ -153,6 +154,15 @@ def test_degenerate_bands():
     g, planes = check(sensors, zones, params)
     assert [p.found for p in planes[0]] == [0, 0, 0]
     assert len(g["ground"]) == 0 and len(g["merged"]) == len(xyz)
+
+
+def test_general_path_gives_the_same(monkeypatch):
+    monkeypatch.setenv("CM_PATH", "classic")
+    rng = np.random.default_rng(26)
+    sensors = [xyzi_cloud(scene(rng, 50_000), rng.uniform(0, 255, 50_000))]
+    params = MergeParams(leaf=(0.1,) * 3, min_points_per_voxel=2, **ROI)
+    g, _ = check(sensors, [FRONT], params, dict(GP, outlier_radius=0.15))
+    assert g["res"].path_flags & 2 == 0
 
 
 def test_off_and_repeatable():
