@@ -627,7 +627,7 @@ int launch_classic(cm_ctx* c, const cm_params* p, int mode, int grid_mode, uint3
         keys_and_sort(c->d_state_o, gm_o, 1, in, nullptr, passes_o);
         prof_mark(c, "outlier_mask");
         cmk_outlier_mask(st, c->d_frame, c->d_state_o, c->keys_a, c->vals_a, c->keys_b, c->vals_b, c->sorted_pts,
-                         c->rows, out, f.n_padded, cls);
+                         c->rows, out, f.n_padded, cls, c->merged_total + 8);
         return CM_OK;
     };
     const bool ground_outl = c->ground_on && mode == 0 && c->ground_outlier_radius > 0.0f;

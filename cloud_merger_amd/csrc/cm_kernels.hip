@@ -968,9 +968,20 @@ __global__ __launch_bounds__(CM_BLOCK) void k_neighbors(const CmFrameDev* __rest
                                                         const float4* __restrict__ sorted_pts,
                                                         const uint2* __restrict__ rows,
                                                         unsigned char* __restrict__ mask,
-                                                        const unsigned char* __restrict__ cls) {
+                                                        const unsigned char* __restrict__ cls,
+                                                        int phase, uint32_t* __restrict__ pend_a,
+                                                        uint32_t* __restrict__ pend_b, uint32_t* __restrict__ pend_c,
+                                                        uint32_t* __restrict__ pend_n) {
+    // Two launches. Phase 0: every point looks along its own row only (its neighbours in the sorted order: no
+    // search, coalesced); most points of a dense scene find their min_neighbors there. Those that do not are
+    // appended, with the count they have, to a list (the free halves of the sort's ping-pong buffers), and
+    // phase 1 runs the search through the eight rows around them over that list only — full waves of hard
+    // cases instead of a few slow lanes holding up every wave. pend_a/pend_b: the two key buffers (the list goes
+    // into the one the sort did not end in); pend_c: a vals buffer (free once the points are gathered).
     if (st->status != CM_DEV_OK) return;
     const uint32_t n = st->n_valid;
+    uint32_t* __restrict__ pend_p = (st->n_passes & 1u) ? pend_a : pend_b;      // the keys array the sort did not end in
+    const uint32_t n_items = phase == 0 ? n : *pend_n;
     const uint32_t dx = static_cast<uint32_t>(st->div_b[0]), dy = static_cast<uint32_t>(st->div_b[1]),
                    dz = static_cast<uint32_t>(st->div_b[2]);
     const uint32_t* __restrict__ keys = pick(st, keys_a, keys_b);
@@ -979,11 +990,21 @@ __global__ __launch_bounds__(CM_BLOCK) void k_neighbors(const CmFrameDev* __rest
     const float cell = 1.0f / fd->inv_cell[0];
     const float fb0 = static_cast<float>(st->min_b[0]), fb1 = static_cast<float>(st->min_b[1]),
                 fb2 = static_cast<float>(st->min_b[2]);
-    for (uint32_t p = blockIdx.x * CM_BLOCK + threadIdx.x; p < n; p += gridDim.x * CM_BLOCK) {
+    __shared__ uint32_t s_pp[CM_TILE];
+    __shared__ unsigned char s_pc[CM_TILE];
+    __shared__ uint32_t s_np, s_base;
+    if (threadIdx.x == 0) s_np = 0;
+    __syncthreads();
+    // phase 0: workgroup b takes points [4096 b, 4096 (b + 1)); phase 1: grid-stride over the list
+    const uint32_t t_begin = phase == 0 ? blockIdx.x * CM_TILE + threadIdx.x : blockIdx.x * CM_BLOCK + threadIdx.x;
+    const uint32_t t_end = phase == 0 ? min(n_items, (blockIdx.x + 1u) * CM_TILE) : n_items;
+    const uint32_t t_step = phase == 0 ? CM_BLOCK : gridDim.x * CM_BLOCK;
+    for (uint32_t t = t_begin; t < t_end; t += t_step) {
+        const uint32_t p = phase == 0 ? t : pend_p[t];
         const uint32_t key = keys[p];
         const float4 me = sorted_pts[p];
         const uint32_t jk = key / dx, i = key - jk * dx, k = jk / dy, j = jk - k * dy;
-        uint32_t cnt = 1;                                         // the point itself (distance 0)
+        uint32_t cnt = phase == 0 ? 1u : pend_c[t];               // phase 0: the point itself (distance 0)
         // cls: neighbours count only inside the point's own class (the ground stage filters every slab's
         // band on its own, like the reference's per-slab outlierRemoval call)
         const uint32_t my_cls = cls ? cls[__float_as_uint(me.w)] : 0u;
@@ -994,7 +1015,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_neighbors(const CmFrameDev* __rest
         };
         // Own row first, outward from the point's own sorted position: the points of its own cell
         // are its immediate neighbours in the sorted order (no search, early exit for most points).
-        {
+        if (phase == 0) {
             const uint32_t lo_key = jk * dx + (i ? i - 1 : 0u), hi_key = jk * dx + ((i + 1 < dx) ? i + 1 : dx - 1);
             for (uint32_t q = p + 1; q < n && cnt <= need; ++q) {
                 if (keys[q] > hi_key) break;
@@ -1005,6 +1026,15 @@ __global__ __launch_bounds__(CM_BLOCK) void k_neighbors(const CmFrameDev* __rest
                 if (keys[q] < lo_key) break;
                 if (test(sorted_pts[q])) ++cnt;
             }
+        }
+        if (phase == 0) {
+            if (cnt > need) mask[__float_as_uint(me.w)] = 1;
+            else {                                             // into the workgroup's share of the list (LDS), flushed below
+                const uint32_t at = atomicAdd(&s_np, 1u);
+                s_pp[at] = p;
+                s_pc[at] = static_cast<unsigned char>(cnt < 255u ? cnt : 255u);
+            }
+            continue;
         }
         if (cnt <= need) {
             // Distance from the point to the faces of its own cell, shrunk by 1 % of a cell so fp32
@@ -1073,6 +1103,15 @@ __global__ __launch_bounds__(CM_BLOCK) void k_neighbors(const CmFrameDev* __rest
             }
         }
         if (cnt > need) mask[__float_as_uint(me.w)] = 1;
+    }
+    if (phase == 0) {                                      // one global add per workgroup, then the copy
+        __syncthreads();
+        if (threadIdx.x == 0) s_base = s_np ? atomicAdd(pend_n, s_np) : 0u;
+        __syncthreads();
+        for (uint32_t q = threadIdx.x; q < s_np; q += CM_BLOCK) {
+            pend_p[s_base + q] = s_pp[q];
+            pend_c[s_base + q] = s_pc[q];
+        }
     }
 }
 
@@ -1175,13 +1214,17 @@ void cmk_keys(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* k
 }
 void cmk_outlier_mask(hipStream_t s, const CmFrameDev* fd, const CmFrameState* st, const uint32_t* keys_a,
                       const uint32_t* vals_a, const uint32_t* keys_b, const uint32_t* vals_b, void* sorted_pts,
-                      void* rows, unsigned char* mask, uint32_t n_padded, const unsigned char* cls) {
+                      void* rows, unsigned char* mask, uint32_t n_padded, const unsigned char* cls, uint32_t* pend_n) {
     const uint32_t blocks = (n_padded + CM_BLOCK * 4 - 1) / (CM_BLOCK * 4);
     CM_LAUNCH(k_gather_sorted, blocks, CM_BLOCK, s, fd, st, vals_a, vals_b, reinterpret_cast<float4*>(sorted_pts));
     CM_LAUNCH(k_row_clear, 1024, CM_BLOCK, s, st, reinterpret_cast<uint2*>(rows));
     CM_LAUNCH(k_row_table, blocks, CM_BLOCK, s, st, keys_a, keys_b, reinterpret_cast<uint2*>(rows));
-    CM_LAUNCH(k_neighbors, (n_padded + CM_BLOCK - 1) / CM_BLOCK, CM_BLOCK, s, fd, st, keys_a, keys_b,
-              reinterpret_cast<const float4*>(sorted_pts), reinterpret_cast<const uint2*>(rows), mask, cls);
+    // pending list: point numbers in the keys buffer the sort did not end in, their counts in the matching vals buffer
+    (void)hipMemsetAsync(pend_n, 0, 4, s);
+    for (int phase = 0; phase < 2; ++phase)
+        CM_LAUNCH(k_neighbors, phase == 0 ? n_padded / CM_TILE : (n_padded + CM_BLOCK - 1) / CM_BLOCK, CM_BLOCK, s, fd, st, keys_a, keys_b,
+                  reinterpret_cast<const float4*>(sorted_pts), reinterpret_cast<const uint2*>(rows), mask, cls, phase,
+                  const_cast<uint32_t*>(keys_a), const_cast<uint32_t*>(keys_b), const_cast<uint32_t*>(vals_a), pend_n);
 }
 void cmk_hist(hipStream_t s, const CmFrameState* st, const uint32_t* keys, uint32_t* hist, uint32_t* grp,
               uint32_t pass, uint32_t n_tiles) {
