@@ -115,7 +115,6 @@ struct cm_ctx {
     float* records = nullptr;            // min/max/count per tile
     bool pred_ok = false;                // a box predicted from an earlier frame's bounds
     float pred_min[3] = {0, 0, 0}, pred_max[3] = {0, 0, 0};
-    int v2_variant = 1;                  // local finish geometry: 1 2048-record tiles (2 workgroups/CU), 2 4096 (1/CU, longer bucket tails)
     uint32_t v2_extra_passes = 0;        // buckets overflowed LDS: sort more bits globally
     uint32_t v2_good_frames = 0;         // bucket-path frames since the last overflow
     uint32_t v2_retry_after = 256;       // ... after this many, try one global pass fewer again (doubles on failure)
@@ -442,7 +441,7 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
     prof_mark(c, "k2_local");
     cmk2_local(st, c->d_frame, state, state_next, c->h_state_dev, ((n_global - 1) & 1u) ? c->rec_b : c->rec_a,
                c->tile_state, reinterpret_cast<uint32_t*>(c->tile_state + (f.n_padded / 1024 + 1)), c->out, c->out_key,
-               c->out_cnt, low_bits, f.n_padded, c->v2_variant);
+               c->out_cnt, low_bits, f.n_padded);
     prof_mark(c, "end");
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_done, st));
@@ -921,7 +920,6 @@ int cm_create(cm_ctx** out, int device, const cm_limits* lim) {
     ok = ok && hipMemset(c->d_state[1], 0, sizeof(CmFrameState)) == hipSuccess;
     ok = ok && hipDeviceSynchronize() == hipSuccess;
     if (const char* pm = getenv("CM_PATH")) c->path_mode = std::strcmp(pm, "classic") == 0 ? 1 : 0;
-    if (const char* lv = getenv("CM_LOCAL_VARIANT")) c->v2_variant = std::atoi(lv) >= 2 ? 2 : 1;
     if (ok) {
         // Probe the device once: lane-ordered returning LDS adds allow the cheap stable ranking.
         // CM_LDS_RANK=0 forces the ballot-match ranking, CM_LDS_RANK=1 skips the probe.

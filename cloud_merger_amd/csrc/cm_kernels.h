@@ -56,7 +56,7 @@ void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, CmFrameState*
                   const float* records, uint32_t n_records, int fold, const unsigned char* mask);
 void cmk2_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next, uint32_t* host_state,
                 const void* rec, unsigned long long* tile_state, uint32_t* ticket, void* out, uint32_t* out_key,
-                uint32_t* out_cnt, uint32_t low_bits, uint32_t n_padded, int variant);
+                uint32_t* out_cnt, uint32_t low_bits, uint32_t n_padded);
 
 // ---- zone-wise ground removal (cm_kernels_ground.hip) ------------------------------------------
 void cmkg_setup(hipStream_t s, const CmGroundDev& g, CmGroundDev* d_ground);

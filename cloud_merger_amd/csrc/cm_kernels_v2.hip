@@ -820,13 +820,9 @@ void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, CmFrameState*
 }
 void cmk2_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next, uint32_t* host_state,
                 const void* rec, unsigned long long* tile_state, uint32_t* ticket, void* out, uint32_t* out_key,
-                uint32_t* out_cnt, uint32_t low_bits, uint32_t n_padded, int variant) {
-    const float4* r = reinterpret_cast<const float4*>(rec);
-    float4* o = reinterpret_cast<float4*>(out);
-    if (variant <= 1)
-        hipLaunchKernelGGL((k2_local<2048, 4096, 512>), dim3(n_padded / 2048), dim3(512), 0, s, fd, st, st_next, host_state,
-                           r, tile_state, ticket, o, out_key, out_cnt, low_bits);
-    else
-        hipLaunchKernelGGL((k2_local<4096, 8192, 1024>), dim3(n_padded / 4096), dim3(1024), 0, s, fd, st, st_next, host_state,
-                           r, tile_state, ticket, o, out_key, out_cnt, low_bits);
+                uint32_t* out_cnt, uint32_t low_bits, uint32_t n_padded) {
+    // 2048-record tiles, room for 4096 (bucket tails up to 2048 records), 512 threads: 42 KB of LDS, three per CU
+    hipLaunchKernelGGL((k2_local<2048, 4096, 512>), dim3(n_padded / 2048), dim3(512), 0, s, fd, st, st_next, host_state,
+                       reinterpret_cast<const float4*>(rec), tile_state, ticket, reinterpret_cast<float4*>(out), out_key,
+                       out_cnt, low_bits);
 }
