@@ -122,6 +122,7 @@ struct cm_ctx {
     bool last_v2 = false, last_predicted = false;
     bool post_bucket = false;            // the frame's pre-stages (ground / outlier removal) run first, then the bucket path
     uint32_t post_g = 0, post_low = 0;
+    uint64_t last_n_merged = 0;          // points that entered the voxel grid in the last finished frame (0: none yet)
     bool last_outl = false;
     int last_gm_o = 0;
     uint32_t last_kb_o = 0;
@@ -548,7 +549,9 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
             // enough that an average bucket (points / 2^(8 g)) stays well inside its LDS capacity; a frame that
             // overflows anyway is handed back and v2_extra_passes adds a pass for the frames after it.
             uint32_t g = 1 + (kb > CM2_MAX_LOW_BITS + 8 ? (kb - CM2_MAX_LOW_BITS - 1) / 8 : 0);
-            while (g < CM_MAX_PASSES && (c->n_in >> (8 * g)) > 256) ++g;
+            // (points: what the last frame kept after crop and masks, plus a quarter, when there was one)
+            const uint64_t est = c->last_n_merged ? std::min<uint64_t>(c->n_in, c->last_n_merged + c->last_n_merged / 4) : c->n_in;
+            while (g < CM_MAX_PASSES && (est >> (8 * g)) > 256) ++g;
             g += c->v2_extra_passes;
             if (g > 1 && 8 * (g - 1) >= kb) g = 0;           // nothing left for the local finish to add
             if (g >= 1 && g <= CM_MAX_PASSES) {
@@ -818,6 +821,7 @@ int wait_frame(cm_ctx* c, cm_result* res) {
             for (int a = 0; a < 3; ++a) leaf[a] = 1.0f / c->frame.inv_leaf[a];
             update_predicted_box(c, h.min_p, h.max_p, leaf);
         }
+        if (h.status == CM_OK) c->last_n_merged = h.n_valid;
         if (h.status == CM_OK) {
             r.n_merged = h.n_valid;
             r.n_out = h.n_out;
