@@ -183,12 +183,12 @@ def main():
         for k, s in enumerate(sensors):
             cmp.set_transform(k, s.q_xyzw, s.t_xyz)
         acc, order, dev_ms = {}, [], []
-        for it in range(args.profile_frames + 2):
+        for it in range(args.profile_frames + 5):
             for k, s in enumerate(sensors):
                 cmp.submit_device(k, dev_clouds[k].data_ptr(), s.n, s.point_step, s.off_x, s.off_y, s.off_z, s.off_i)
             cmp.merge_voxelize_async(cparams)
             r = cmp.wait()
-            if it < 2:
+            if it < 5:
                 continue
             dev_ms.append(r.device_ms)
             for name, ms in cmp.stage_times():
