@@ -395,7 +395,7 @@ int bootstrap_box(cm_ctx* c) {
 // The launch sequence of cm_kernels_v2.hip for the frame in c->frame: n_global 8-bit passes over the
 // key bits above `low_bits`, then the local finish.
 int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits, const unsigned char* mask,
-                  const CmFrameState* st_outlier) {
+                  const CmFrameState* st_outlier, int mode = 0) {
     CmFrameDev& f = c->frame;
     hipStream_t st = c->stream;
     const size_t npad = c->cap_padded;
@@ -412,9 +412,11 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
     }
     CmFrameState* state = c->d_state[c->cur];
     CmFrameState* state_next = c->d_state[c->cur ^ 1];
-    c->from_crop = grid_mode == 1;
+    const bool predicted = grid_mode == 2 && mode == 0;   // mode 1: the bounds handed in are the fused cloud's own
+    c->from_crop = grid_mode == 1 || (grid_mode == 2 && !predicted);
     c->last_v2 = true;
-    c->last_predicted = grid_mode == 2;
+    c->last_predicted = predicted;
+    if (mode == 1 && !c->partial) HIP_TRY(c, hipMalloc(&c->partial, static_cast<size_t>(c->cap_padded) * 32));
     const uint32_t nt = f.n_tiles;
     const uint32_t n_groups = (nt + CM_GROUP - 1) / CM_GROUP;
     const uint32_t gw = n_groups * CM_RADIX;
@@ -427,7 +429,8 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
     c->frame_mask = mask;
     prof_mark(c, "k2_hist0");
     cmk2_hist0(st, c->d_frame, state, c->hist, grp0, grp0_next, c->grp + 2 * gstride, gw, static_cast<uint32_t>(gstride),
-               c->tile_state, f.n_padded / 1024 + 2, c->records, grid_mode, low_bits, n_global, nt, mask, st_outlier);
+               c->tile_state, f.n_padded / 1024 + 2, c->records, grid_mode, predicted ? 1 : 0, low_bits, n_global, nt, mask,
+               st_outlier);
     for (uint32_t pass = 0; pass < n_global; ++pass) {
         uint32_t* grp = pass == 0 ? grp0 : c->grp + 2 * gstride + static_cast<size_t>(pass - 1) * gw;
         if (pass > 0) { prof_mark(c, "k2_hist"); cmk2_hist(st, state, c->dig, c->hist, grp, nt); }
@@ -437,12 +440,12 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
         void* out = (pass & 1u) ? c->rec_b : c->rec_a;
         cmk2_scatter(st, pass == 0, c->d_frame, state, in, out, c->dig, c->hist, grp, big ? c->totals : nullptr,
                      low_bits + 8 * pass, pass + 1 < n_global ? low_bits + 8 * (pass + 1) : 32u, nt, n_groups,
-                     f.n_padded, c->records, nt, grid_mode == 2 ? 1 : 0, mask);
+                     f.n_padded, c->records, nt, predicted ? 1 : 0, mask);
     }
     prof_mark(c, "k2_local");
     cmk2_local(st, c->d_frame, state, state_next, c->h_state_dev, ((n_global - 1) & 1u) ? c->rec_b : c->rec_a,
                c->tile_state, reinterpret_cast<uint32_t*>(c->tile_state + (f.n_padded / 1024 + 1)), c->out, c->out_key,
-               c->out_cnt, low_bits, f.n_padded);
+               c->out_cnt, mode == 1 ? c->partial : nullptr, low_bits, f.n_padded);
     prof_mark(c, "end");
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_done, st));
@@ -524,7 +527,7 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
     const bool pre = outl || c->ground_on;
     c->post_bucket = false;
     c->last_outl = outl; c->last_gm_o = gm_o; c->last_kb_o = kb_o;
-    bool want_v2 = c->path_mode != 1 && mode == 0 && c->lds_rank && (!pre || grid_mode == 1);
+    bool want_v2 = c->path_mode != 1 && (mode == 0 || mode == 1) && c->lds_rank && (!pre || grid_mode == 1);
     if (want_v2 && c->v2_off_frames) { --c->v2_off_frames; want_v2 = false; }
     if (want_v2) {
         int gm = grid_mode;
@@ -542,9 +545,10 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
             }
         }
         if (gm == 1 && !box_grid(p->crop_min, p->crop_max, inv_leaf, &kb, f.box_min_b, f.box_div_b)) gm = 0;
+        if (gm == 2 && mode == 1 && !box_grid(bounds, bounds + 3, inv_leaf, &kb, f.box_min_b, f.box_div_b)) gm = 0;
         if (gm != 0) {
             f.box_key_bits = kb;
-            f.box_predicted = gm == 2 ? 1u : 0u;
+            f.box_predicted = (gm == 2 && mode == 0) ? 1u : 0u;
             // Global passes: enough that at most CM2_MAX_LOW_BITS index bits are left to the local finish, and
             // enough that an average bucket (points / 2^(8 g)) stays well inside its LDS capacity; a frame that
             // overflows anyway is handed back and v2_extra_passes adds a pass for the frames after it.
@@ -556,7 +560,7 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
             if (g > 1 && 8 * (g - 1) >= kb) g = 0;           // nothing left for the local finish to add
             if (g >= 1 && g <= CM_MAX_PASSES) {
                 const uint32_t low = kb > 8 * g ? kb - 8 * g : 0;
-                if (!pre) return launch_bucket(c, gm, g, low, nullptr, nullptr);
+                if (!pre) return launch_bucket(c, gm, g, low, nullptr, nullptr, mode);
                 c->post_bucket = true; c->post_g = g; c->post_low = low;
             }
         }
@@ -759,9 +763,10 @@ int wait_frame(cm_ctx* c, cm_result* res) {
                     for (int a = 0; a < 3; ++a) c->frame.inv_cell[a] = prev.inv_cell[a];
                     c->frame.outlier_r2 = prev.outlier_r2;
                     c->frame.outlier_min_nb = prev.outlier_min_nb;
+                    for (int a = 0; a < 3; ++a) { c->frame.ext_min[a] = prev.ext_min[a]; c->frame.ext_max[a] = prev.ext_max[a]; }
                     c->post_bucket = false;
                     if (e == CM_OK && c->frame.n_padded)
-                        e = launch_classic(c, &pr, 0, c->last_grid_mode, c->last_key_bits, c->last_outl, c->last_gm_o, c->last_kb_o);
+                        e = launch_classic(c, &pr, c->last_mode, c->last_grid_mode, c->last_key_bits, c->last_outl, c->last_gm_o, c->last_kb_o);
                     else if (e == CM_OK)
                         e = CM_NOT_READY;
                     if (e != CM_OK) { c->pending = false; return e == CM_NOT_READY ? fail(c, CM_INTERNAL, "frame could not be redone: its clouds were cleared") : e; }

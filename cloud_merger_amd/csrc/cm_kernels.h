@@ -45,7 +45,7 @@ void cmk_merged(hipStream_t s, const CmFrameDev* fd, uint32_t* tile_counts, uint
 // ---- bucket path (cm_kernels_v2.hip) --------------------------------------------------------
 void cmk2_hist0(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* hist, uint32_t* grp_acc,
                 uint32_t* grp_clear_a, uint32_t* grp_clear_b, uint32_t n_group_words, uint32_t n_clear_a_words,
-                unsigned long long* tile_state, uint32_t n_tile_state, float* records, int grid_mode,
+                unsigned long long* tile_state, uint32_t n_tile_state, float* records, int grid_mode, int check_box,
                 uint32_t shift0, uint32_t n_global_passes, uint32_t n_tiles, const unsigned char* mask,
                 const CmFrameState* st_outlier);
 void cmk2_hist(hipStream_t s, const CmFrameState* st, const unsigned char* dig, uint32_t* hist, uint32_t* grp,
@@ -56,7 +56,7 @@ void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, CmFrameState*
                   const float* records, uint32_t n_records, int fold, const unsigned char* mask);
 void cmk2_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next, uint32_t* host_state,
                 const void* rec, unsigned long long* tile_state, uint32_t* ticket, void* out, uint32_t* out_key,
-                uint32_t* out_cnt, uint32_t low_bits, uint32_t n_padded);
+                uint32_t* out_cnt, void* partial_out, uint32_t low_bits, uint32_t n_padded);
 
 // ---- zone-wise ground removal (cm_kernels_ground.hip) ------------------------------------------
 void cmkg_setup(hipStream_t s, const CmGroundDev& g, CmGroundDev* d_ground);

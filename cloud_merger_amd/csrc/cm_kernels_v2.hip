@@ -126,7 +126,7 @@ __global__ __launch_bounds__(CM2_BLOCK) void k2_hist0(const CmFrameDev* __restri
                                                       unsigned long long* __restrict__ tile_state,
                                                       uint32_t n_tile_state,
                                                       float* __restrict__ records,
-                                                      int grid_mode, uint32_t shift0, uint32_t n_global_passes,
+                                                      int grid_mode, int check_box, uint32_t shift0, uint32_t n_global_passes,
                                                       const unsigned char* __restrict__ mask,
                                                       const CmFrameState* __restrict__ st_outlier) {
     __shared__ uint32_t lh[CM_RADIX];
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(CM2_BLOCK) void k2_hist0(const CmFrameDev* __restri
         st->n_passes = n_global_passes;
     }
     const BoxGrid b = box_grid_of(fd);
-    const bool predicted = grid_mode == 2;
+    const bool predicted = check_box != 0;        // the box is a prediction: verify every point, record the true bounds
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t slot0 = tile * CM_TILE + w * (64 * CM2_ITEMS) + lane;
@@ -479,6 +479,7 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
                                                        float4* __restrict__ out,
                                                        uint32_t* __restrict__ out_key,
                                                        uint32_t* __restrict__ out_cnt,
+                                                       float4* __restrict__ partial_out,
                                                        uint32_t low_bits) {
     constexpr int LWAVES = LBLOCK / 64, LITEMS = (LCAP + LBLOCK - 1) / LBLOCK, EXT0 = LBLOCK < 256 ? LBLOCK : 256;
     constexpr int BINS = 1024, HWORDS = BINS / 2;          // two 16-bit counters per LDS word
@@ -518,7 +519,8 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
     __syncthreads();
     const BoxGrid b = b0;
     const uint32_t L = low_bits;
-    const uint32_t min_pts = fd->min_pts > 1 ? fd->min_pts : 1u;
+    // partial_out: this GPU's share of a fused cloud — per-voxel sums and counts, no threshold, no division (§6)
+    const uint32_t min_pts = (!partial_out && fd->min_pts > 1) ? fd->min_pts : 1u;
 
     // ---- load: the nominal tile, the key before it, and the first records after it
     const uint32_t base = tile * LT;
@@ -777,7 +779,11 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
     uint32_t slot = tile_off + my_slot;
 #pragma unroll
     for (int j = 0; j < LITEMS; ++j) {
-        if (vlen[j]) {
+        if (vlen[j] && partial_out) {                      // cm_partial_entry: key, count, sx, sy | sz, si, 0, 0
+            partial_out[2 * static_cast<size_t>(slot)] = make_float4(__uint_as_float(sk[si[vstart[j]]]), __uint_as_float(acc[j].c), acc[j].x, acc[j].y);
+            partial_out[2 * static_cast<size_t>(slot) + 1] = make_float4(acc[j].z, acc[j].i, 0.f, 0.f);
+            ++slot;
+        } else if (vlen[j]) {
             const float c = static_cast<float>(acc[j].c);
             const float rc = __frcp_rn(c);                  // RN(1/c), shared by the four quotients
             float4 o;
@@ -794,11 +800,11 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
 
 void cmk2_hist0(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* hist, uint32_t* grp_acc,
                 uint32_t* grp_clear_a, uint32_t* grp_clear_b, uint32_t n_group_words, uint32_t n_clear_a_words,
-                unsigned long long* tile_state, uint32_t n_tile_state, float* records, int grid_mode,
+                unsigned long long* tile_state, uint32_t n_tile_state, float* records, int grid_mode, int check_box,
                 uint32_t shift0, uint32_t n_global_passes, uint32_t n_tiles, const unsigned char* mask,
                 const CmFrameState* st_outlier) {
     hipLaunchKernelGGL(k2_hist0, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, st, hist, grp_acc, grp_clear_a, grp_clear_b,
-                       n_group_words, n_clear_a_words, tile_state, n_tile_state, records, grid_mode, shift0,
+                       n_group_words, n_clear_a_words, tile_state, n_tile_state, records, grid_mode, check_box, shift0,
                        n_global_passes, mask, st_outlier);
 }
 void cmk2_hist(hipStream_t s, const CmFrameState* st, const unsigned char* dig, uint32_t* hist, uint32_t* grp,
@@ -820,9 +826,9 @@ void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, CmFrameState*
 }
 void cmk2_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next, uint32_t* host_state,
                 const void* rec, unsigned long long* tile_state, uint32_t* ticket, void* out, uint32_t* out_key,
-                uint32_t* out_cnt, uint32_t low_bits, uint32_t n_padded) {
+                uint32_t* out_cnt, void* partial_out, uint32_t low_bits, uint32_t n_padded) {
     // 2048-record tiles, room for 4096 (bucket tails up to 2048 records), 512 threads: 42 KB of LDS, three per CU
     hipLaunchKernelGGL((k2_local<2048, 4096, 512>), dim3(n_padded / 2048), dim3(512), 0, s, fd, st, st_next, host_state,
                        reinterpret_cast<const float4*>(rec), tile_state, ticket, reinterpret_cast<float4*>(out), out_key,
-                       out_cnt, low_bits);
+                       out_cnt, reinterpret_cast<float4*>(partial_out), low_bits);
 }

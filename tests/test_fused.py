@@ -107,8 +107,10 @@ def test_table_exchange_gloo_world2():
 
 # ---- GPU: two contexts as two ranks -----------------------------------------------------------
 @pytest.mark.gpu
+@pytest.mark.parametrize("path", ["auto", "classic"])
 @pytest.mark.parametrize("crop", [True, False])
-def test_two_rank_fused_cloud_on_one_gpu(crop):
+def test_two_rank_fused_cloud_on_one_gpu(crop, path, monkeypatch):
+    monkeypatch.setenv("CM_PATH", path)         # auto: the ranks' partial tables come from the bucket path
     from cloud_merger_amd import capi
     if crop:
         sensors, params = synth.config3(n_per_sensor=150_000, n_sensors=6, min_pts=2, leaf=0.05)
@@ -130,6 +132,7 @@ def test_two_rank_fused_cloud_on_one_gpu(crop):
     for cm in cms:
         res = cm.merge_partial(params, bounds)
         assert res.status == capi.OK
+        assert bool(res.path_flags & 2) == (path == "auto") and res.path_flags & 4 == 0
         parts.append(cm.partial_device())
     # sanity of one table against the numpy restatement (crop grid only)
     if crop:
