@@ -132,7 +132,7 @@ def test_two_rank_fused_cloud_on_one_gpu(crop, path, monkeypatch):
     for cm in cms:
         res = cm.merge_partial(params, bounds)
         assert res.status == capi.OK
-        assert bool(res.path_flags & 2) == (path == "auto") and res.path_flags & 4 == 0
+        assert bool(res.path_flags & 2) == (path == "auto" and bool(res.path_flags & 1)) and res.path_flags & 4 == 0
         parts.append(cm.partial_device())
     # sanity of one table against the numpy restatement (crop grid only)
     if crop:

@@ -120,7 +120,7 @@ def test_config1_plumbing():
 def test_config2_scaled(min_pts, sort_path):
     sensors, params = synth.config2(n_per_sensor=150_000, min_pts=min_pts)
     g, rep = check_against_oracle(sensors, params, exact_small_runs=True)
-    want = (BUCKET | PREDICTED) if sort_path == "auto" else 0      # no crop box: box predicted from the bounds
+    want = (BUCKET | PREDICTED) if (sort_path == "auto" and g["res"].path_flags & 1) else 0      # no crop box: box predicted from the bounds
     assert g["res"].path_flags & (BUCKET | PREDICTED) == want
 
 
@@ -416,7 +416,7 @@ def test_outlier_removal_reference_parameters(sort_path):
                          outlier_min_neighbors=1)
     g, rep = check_against_oracle(sensors, params)
     assert g["res"].bounds_from_crop == 1 and 0 < g["res"].n_merged
-    assert bool(g["res"].path_flags & BUCKET) == (sort_path == "auto")     # crop box: the voxel stage after the filter takes the bucket path
+    assert bool(g["res"].path_flags & BUCKET) == (sort_path == "auto" and bool(g["res"].path_flags & 1))     # crop box: the voxel stage after the filter takes the bucket path
 
 
 def test_outlier_removal_small_known_case():
@@ -572,7 +572,8 @@ def test_predicted_box_miss_is_redone_and_learned(sort_path):
             assert list(g["res"].min_b) == list(rep.min_b) and list(g["res"].div_b) == list(rep.div_b)
             assert_centroids_close(g["out"], xyzi_of(out))
             flags.append(g["res"].path_flags & (BUCKET | PREDICTED | REDONE))
-    if sort_path == "classic":
+            lds_rank = g["res"].path_flags & 1
+    if sort_path == "classic" or not lds_rank:          # (no bucket path without the lane-ordered LDS ranking)
         assert flags == [0] * 5
     else:
         bp = BUCKET | PREDICTED
@@ -595,7 +596,8 @@ def test_bucket_too_large_for_lds_is_redone(sort_path):
             assert np.array_equal(g["counts"], rep.counts) and rep.counts.max() >= 5_000
             assert_centroids_close(g["out"], xyzi_of(out))
             flags.append(g["res"].path_flags & (BUCKET | REDONE))
-    if sort_path == "classic":
+            lds_rank = g["res"].path_flags & 1
+    if sort_path == "classic" or not lds_rank:
         assert flags == [0, 0, 0]
     else:
         assert flags[0] == REDONE and all(f in (BUCKET, REDONE, 0) for f in flags[1:])
@@ -628,5 +630,5 @@ def test_bucket_path_one_to_three_global_passes(leaf, half, n_pass, sort_path):
     params = MergeParams(leaf=(leaf,) * 3, min_points_per_voxel=0, crop_min=tuple(-half), crop_max=tuple(half))
     g, rep = check_against_oracle(sensors, params, exact_small_runs=True)
     assert g["res"].bounds_from_crop == 1
-    if sort_path == "auto":
+    if sort_path == "auto" and g["res"].path_flags & 1:
         assert g["res"].path_flags & BUCKET and g["res"].sort_passes == n_pass
