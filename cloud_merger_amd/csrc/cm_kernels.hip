@@ -961,6 +961,89 @@ __global__ __launch_bounds__(CM_BLOCK) void k_row_table(const CmFrameState* __re
     }
 }
 
+// Neighbour search, first launch: every point looks along its own row only — its neighbours in the sorted
+// order — inside an LDS window (1024 points of the workgroup + 256 on either side), so the scan costs no
+// dependent global loads. Points that reach min_neighbors are marked kept; the others go, with the count they
+// have, onto a list (per workgroup in LDS, one global add per workgroup, then the copy) for k_neighbors. A scan
+// that runs into the edge of the window before its cell range ends is flagged: k_neighbors redoes that row scan
+// through global memory. pend_a/pend_b: the two key buffers of the sort (the list goes into the one the sort did
+// not end in); pend_c: a vals buffer (free once the points are gathered).
+#define CM_NB_TILE 1024
+#define CM_NB_HALO 256
+__global__ __launch_bounds__(CM_BLOCK) void k_neighbors_row(const CmFrameDev* __restrict__ fd,
+                                                            const CmFrameState* __restrict__ st,
+                                                            const uint32_t* __restrict__ keys_a,
+                                                            const uint32_t* __restrict__ keys_b,
+                                                            const float4* __restrict__ sorted_pts,
+                                                            unsigned char* __restrict__ mask,
+                                                            const unsigned char* __restrict__ cls,
+                                                            uint32_t* __restrict__ pend_a, uint32_t* __restrict__ pend_b,
+                                                            uint32_t* __restrict__ pend_c, uint32_t* __restrict__ pend_n) {
+    __shared__ uint32_t wk[CM_NB_TILE + 2 * CM_NB_HALO];
+    __shared__ float4 wp[CM_NB_TILE + 2 * CM_NB_HALO];
+    __shared__ uint32_t s_pp[CM_NB_TILE], s_pc[CM_NB_TILE];
+    __shared__ uint32_t s_np, s_base;
+    if (st->status != CM_DEV_OK) return;
+    const uint32_t n = st->n_valid;
+    const uint32_t base = blockIdx.x * CM_NB_TILE;
+    if (base >= n) return;
+    uint32_t* __restrict__ pend_p = (st->n_passes & 1u) ? pend_a : pend_b;
+    const uint32_t* __restrict__ keys = pick(st, keys_a, keys_b);
+    const uint32_t dx = static_cast<uint32_t>(st->div_b[0]);
+    const float r2 = fd->outlier_r2;
+    const uint32_t need = fd->outlier_min_nb;
+    const uint32_t w0 = base >= CM_NB_HALO ? base - CM_NB_HALO : 0u;
+    const uint32_t w1 = min(n, base + CM_NB_TILE + CM_NB_HALO);
+    const uint32_t wn = w1 - w0;
+    if (threadIdx.x == 0) s_np = 0;
+    for (uint32_t q = threadIdx.x; q < wn; q += CM_BLOCK) { wk[q] = keys[w0 + q]; wp[q] = sorted_pts[w0 + q]; }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < CM_NB_TILE / CM_BLOCK; ++u) {
+        const uint32_t p = base + u * CM_BLOCK + threadIdx.x;
+        if (p >= n) continue;
+        const uint32_t lp = p - w0;
+        const uint32_t key = wk[lp];
+        const float4 me = wp[lp];
+        const uint32_t jk = key / dx, i = key - jk * dx;
+        const uint32_t lo_key = jk * dx + (i ? i - 1 : 0u), hi_key = jk * dx + ((i + 1 < dx) ? i + 1 : dx - 1);
+        const uint32_t my_cls = cls ? cls[__float_as_uint(me.w)] : 0u;
+        auto test = [&](const float4& pt) {
+            const float ex = __fsub_rn(me.x, pt.x), ey = __fsub_rn(me.y, pt.y), ez = __fsub_rn(me.z, pt.z);
+            const bool near = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez)) < r2;
+            return near && (!cls || cls[__float_as_uint(pt.w)] == my_cls);
+        };
+        uint32_t cnt = 1;                                      // the point itself (distance 0)
+        bool incomplete = false;
+        for (uint32_t q = lp + 1; cnt <= need; ++q) {
+            if (q >= wn) { incomplete = w1 < n; break; }
+            if (wk[q] > hi_key) break;
+            if (test(wp[q])) ++cnt;
+        }
+        for (uint32_t q = lp; cnt <= need;) {
+            if (q == 0) { incomplete = incomplete || w0 > 0; break; }
+            --q;
+            if (wk[q] < lo_key) break;
+            if (test(wp[q])) ++cnt;
+        }
+        if (cnt > need) mask[__float_as_uint(me.w)] = 1;
+        else {
+            const uint32_t at = atomicAdd(&s_np, 1u);
+            s_pp[at] = p;
+            s_pc[at] = incomplete ? 0x80000000u : cnt;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_np ? atomicAdd(pend_n, s_np) : 0u;
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < s_np; q += CM_BLOCK) {
+        pend_p[s_base + q] = s_pp[q];
+        pend_c[s_base + q] = s_pc[q];
+    }
+}
+
+// Second launch: the points on the list — the eight rows around each (and its own row again where the first
+// launch could not finish it): full waves of hard cases instead of a few slow lanes holding up every wave.
 __global__ __launch_bounds__(CM_BLOCK) void k_neighbors(const CmFrameDev* __restrict__ fd,
                                                         const CmFrameState* __restrict__ st,
                                                         const uint32_t* __restrict__ keys_a,
@@ -969,19 +1052,13 @@ __global__ __launch_bounds__(CM_BLOCK) void k_neighbors(const CmFrameDev* __rest
                                                         const uint2* __restrict__ rows,
                                                         unsigned char* __restrict__ mask,
                                                         const unsigned char* __restrict__ cls,
-                                                        int phase, uint32_t* __restrict__ pend_a,
+                                                        uint32_t* __restrict__ pend_a,
                                                         uint32_t* __restrict__ pend_b, uint32_t* __restrict__ pend_c,
                                                         uint32_t* __restrict__ pend_n) {
-    // Two launches. Phase 0: every point looks along its own row only (its neighbours in the sorted order: no
-    // search, coalesced); most points of a dense scene find their min_neighbors there. Those that do not are
-    // appended, with the count they have, to a list (the free halves of the sort's ping-pong buffers), and
-    // phase 1 runs the search through the eight rows around them over that list only — full waves of hard
-    // cases instead of a few slow lanes holding up every wave. pend_a/pend_b: the two key buffers (the list goes
-    // into the one the sort did not end in); pend_c: a vals buffer (free once the points are gathered).
     if (st->status != CM_DEV_OK) return;
     const uint32_t n = st->n_valid;
     uint32_t* __restrict__ pend_p = (st->n_passes & 1u) ? pend_a : pend_b;      // the keys array the sort did not end in
-    const uint32_t n_items = phase == 0 ? n : *pend_n;
+    const uint32_t n_items = *pend_n;
     const uint32_t dx = static_cast<uint32_t>(st->div_b[0]), dy = static_cast<uint32_t>(st->div_b[1]),
                    dz = static_cast<uint32_t>(st->div_b[2]);
     const uint32_t* __restrict__ keys = pick(st, keys_a, keys_b);
@@ -990,21 +1067,14 @@ __global__ __launch_bounds__(CM_BLOCK) void k_neighbors(const CmFrameDev* __rest
     const float cell = 1.0f / fd->inv_cell[0];
     const float fb0 = static_cast<float>(st->min_b[0]), fb1 = static_cast<float>(st->min_b[1]),
                 fb2 = static_cast<float>(st->min_b[2]);
-    __shared__ uint32_t s_pp[CM_TILE];
-    __shared__ unsigned char s_pc[CM_TILE];
-    __shared__ uint32_t s_np, s_base;
-    if (threadIdx.x == 0) s_np = 0;
-    __syncthreads();
-    // phase 0: workgroup b takes points [4096 b, 4096 (b + 1)); phase 1: grid-stride over the list
-    const uint32_t t_begin = phase == 0 ? blockIdx.x * CM_TILE + threadIdx.x : blockIdx.x * CM_BLOCK + threadIdx.x;
-    const uint32_t t_end = phase == 0 ? min(n_items, (blockIdx.x + 1u) * CM_TILE) : n_items;
-    const uint32_t t_step = phase == 0 ? CM_BLOCK : gridDim.x * CM_BLOCK;
-    for (uint32_t t = t_begin; t < t_end; t += t_step) {
-        const uint32_t p = phase == 0 ? t : pend_p[t];
+    for (uint32_t t = blockIdx.x * CM_BLOCK + threadIdx.x; t < n_items; t += gridDim.x * CM_BLOCK) {
+        const uint32_t p = pend_p[t];
+        const uint32_t pc = pend_c[t];
+        const bool redo_row = (pc >> 31) != 0;                    // the first launch ran out of its LDS window
         const uint32_t key = keys[p];
         const float4 me = sorted_pts[p];
         const uint32_t jk = key / dx, i = key - jk * dx, k = jk / dy, j = jk - k * dy;
-        uint32_t cnt = phase == 0 ? 1u : pend_c[t];               // phase 0: the point itself (distance 0)
+        uint32_t cnt = redo_row ? 1u : pc;                        // 1: the point itself (distance 0)
         // cls: neighbours count only inside the point's own class (the ground stage filters every slab's
         // band on its own, like the reference's per-slab outlierRemoval call)
         const uint32_t my_cls = cls ? cls[__float_as_uint(me.w)] : 0u;
@@ -1015,7 +1085,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_neighbors(const CmFrameDev* __rest
         };
         // Own row first, outward from the point's own sorted position: the points of its own cell
         // are its immediate neighbours in the sorted order (no search, early exit for most points).
-        if (phase == 0) {
+        if (redo_row) {
             const uint32_t lo_key = jk * dx + (i ? i - 1 : 0u), hi_key = jk * dx + ((i + 1 < dx) ? i + 1 : dx - 1);
             for (uint32_t q = p + 1; q < n && cnt <= need; ++q) {
                 if (keys[q] > hi_key) break;
@@ -1026,15 +1096,6 @@ __global__ __launch_bounds__(CM_BLOCK) void k_neighbors(const CmFrameDev* __rest
                 if (keys[q] < lo_key) break;
                 if (test(sorted_pts[q])) ++cnt;
             }
-        }
-        if (phase == 0) {
-            if (cnt > need) mask[__float_as_uint(me.w)] = 1;
-            else {                                             // into the workgroup's share of the list (LDS), flushed below
-                const uint32_t at = atomicAdd(&s_np, 1u);
-                s_pp[at] = p;
-                s_pc[at] = static_cast<unsigned char>(cnt < 255u ? cnt : 255u);
-            }
-            continue;
         }
         if (cnt <= need) {
             // Distance from the point to the faces of its own cell, shrunk by 1 % of a cell so fp32
@@ -1103,15 +1164,6 @@ __global__ __launch_bounds__(CM_BLOCK) void k_neighbors(const CmFrameDev* __rest
             }
         }
         if (cnt > need) mask[__float_as_uint(me.w)] = 1;
-    }
-    if (phase == 0) {                                      // one global add per workgroup, then the copy
-        __syncthreads();
-        if (threadIdx.x == 0) s_base = s_np ? atomicAdd(pend_n, s_np) : 0u;
-        __syncthreads();
-        for (uint32_t q = threadIdx.x; q < s_np; q += CM_BLOCK) {
-            pend_p[s_base + q] = s_pp[q];
-            pend_c[s_base + q] = s_pc[q];
-        }
     }
 }
 
@@ -1219,12 +1271,16 @@ void cmk_outlier_mask(hipStream_t s, const CmFrameDev* fd, const CmFrameState* s
     CM_LAUNCH(k_gather_sorted, blocks, CM_BLOCK, s, fd, st, vals_a, vals_b, reinterpret_cast<float4*>(sorted_pts));
     CM_LAUNCH(k_row_clear, 1024, CM_BLOCK, s, st, reinterpret_cast<uint2*>(rows));
     CM_LAUNCH(k_row_table, blocks, CM_BLOCK, s, st, keys_a, keys_b, reinterpret_cast<uint2*>(rows));
-    // pending list: point numbers in the keys buffer the sort did not end in, their counts in the matching vals buffer
+    // pending list: point numbers in the keys buffer the sort did not end in, their counts in a vals buffer
     (void)hipMemsetAsync(pend_n, 0, 4, s);
-    for (int phase = 0; phase < 2; ++phase)
-        CM_LAUNCH(k_neighbors, phase == 0 ? n_padded / CM_TILE : (n_padded + CM_BLOCK - 1) / CM_BLOCK, CM_BLOCK, s, fd, st, keys_a, keys_b,
-                  reinterpret_cast<const float4*>(sorted_pts), reinterpret_cast<const uint2*>(rows), mask, cls, phase,
-                  const_cast<uint32_t*>(keys_a), const_cast<uint32_t*>(keys_b), const_cast<uint32_t*>(vals_a), pend_n);
+    uint32_t* pa = const_cast<uint32_t*>(keys_a);
+    uint32_t* pb = const_cast<uint32_t*>(keys_b);
+    uint32_t* pc = const_cast<uint32_t*>(vals_a);
+    const float4* sp = reinterpret_cast<const float4*>(sorted_pts);
+    CM_LAUNCH(k_neighbors_row, (n_padded + CM_NB_TILE - 1) / CM_NB_TILE, CM_BLOCK, s, fd, st, keys_a, keys_b, sp, mask, cls,
+              pa, pb, pc, pend_n);
+    CM_LAUNCH(k_neighbors, (n_padded + CM_BLOCK - 1) / CM_BLOCK, CM_BLOCK, s, fd, st, keys_a, keys_b, sp,
+              reinterpret_cast<const uint2*>(rows), mask, cls, pa, pb, pc, pend_n);
 }
 void cmk_hist(hipStream_t s, const CmFrameState* st, const uint32_t* keys, uint32_t* hist, uint32_t* grp,
               uint32_t pass, uint32_t n_tiles) {
