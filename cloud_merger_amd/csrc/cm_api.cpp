@@ -119,6 +119,9 @@ struct cm_ctx {
     uint32_t v2_good_frames = 0;         // bucket-path frames since the last overflow
     uint32_t v2_retry_after = 256;       // ... after this many, try one global pass fewer again (doubles on failure)
     uint32_t v2_off_frames = 0;          // ... or give the path a rest
+    uint32_t pre_bucket_off = 0;         // frames for which the outlier stage sorts with the general kernels (a bucket overflowed)
+    uint32_t pre_bucket_backoff = 16;
+    bool pre_bucket = false;             // this frame's outlier stage may sort with the bucket kernels
     bool last_v2 = false, last_predicted = false;
     bool post_bucket = false;            // the frame's pre-stages (ground / outlier removal) run first, then the bucket path
     uint32_t post_g = 0, post_low = 0;
@@ -394,16 +397,32 @@ int bootstrap_box(cm_ctx* c) {
 
 // The launch sequence of cm_kernels_v2.hip for the frame in c->frame: n_global 8-bit passes over the
 // key bits above `low_bits`, then the local finish.
-int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits, const unsigned char* mask,
-                  const CmFrameState* st_outlier, int mode = 0) {
-    CmFrameDev& f = c->frame;
-    hipStream_t st = c->stream;
+int bucket_buffers(cm_ctx* c) {
     const size_t npad = c->cap_padded;
     if (!c->rec_a) HIP_TRY(c, hipMalloc(&c->rec_a, npad * 16));
     if (!c->rec_b) HIP_TRY(c, hipMalloc(&c->rec_b, npad * 16));
     if (!c->dig) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->dig), npad));
     if (!c->tile_state) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->tile_state), (npad / 1024 + 2) * 8));
     if (!c->records) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->records), static_cast<size_t>(c->cap_tiles) * 32));
+    return CM_OK;
+}
+
+// Global passes for keys of kb bits over about `est` points: enough that at most CM2_MAX_LOW_BITS index bits are
+// left to the local finish, and enough that an average bucket (points / 2^(8 g)) stays well inside its LDS
+// capacity. 0: the bucket kernels do not fit this grid.
+uint32_t bucket_passes(uint32_t kb, uint64_t est, uint32_t extra) {
+    uint32_t g = 1 + (kb > CM2_MAX_LOW_BITS + 8 ? (kb - CM2_MAX_LOW_BITS - 1) / 8 : 0);
+    while (g < CM_MAX_PASSES && (est >> (8 * g)) > 256) ++g;
+    g += extra;
+    if (g > 1 && 8 * (g - 1) >= kb) return 0;         // nothing left for the local finish to add
+    return g <= CM_MAX_PASSES ? g : 0;
+}
+
+int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits, const unsigned char* mask,
+                  const CmFrameState* st_outlier, int mode = 0) {
+    CmFrameDev& f = c->frame;
+    hipStream_t st = c->stream;
+    { const int e = bucket_buffers(c); if (e != CM_OK) return e; }
     if (!c->frame_uploaded_valid || std::memcmp(&f, &c->frame_uploaded, sizeof f) != 0) {
         prof_mark(c, "k_setup");
         cmk_setup(st, f, c->d_frame);
@@ -425,7 +444,6 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
     uint32_t* grp0 = c->grp + gstride * (c->frame_seq & 1u);
     uint32_t* grp0_next = c->grp + gstride * ((c->frame_seq & 1u) ^ 1u);
     ++c->frame_seq;
-    c->h_state->err = 0;                               // error words are written straight into the host record
     c->frame_mask = mask;
     prof_mark(c, "k2_hist0");
     cmk2_hist0(st, c->d_frame, state, c->hist, grp0, grp0_next, c->grp + 2 * gstride, gw, static_cast<uint32_t>(gstride),
@@ -525,7 +543,9 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
     // Frames with pre-stages (ground / outlier removal, which leave a keep-mask) can use it too when the crop box
     // fixes the grid: the pre-stages run first (launch_classic), then the bucket path takes the voxel stage.
     const bool pre = outl || c->ground_on;
+    c->h_state->err = 0;                     // the bucket kernels write error words straight into the host record
     c->post_bucket = false;
+    c->pre_bucket = false;
     c->last_outl = outl; c->last_gm_o = gm_o; c->last_kb_o = kb_o;
     bool want_v2 = c->path_mode != 1 && (mode == 0 || mode == 1) && c->lds_rank && (!pre || grid_mode == 1);
     if (want_v2 && c->v2_off_frames) { --c->v2_off_frames; want_v2 = false; }
@@ -549,19 +569,19 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
         if (gm != 0) {
             f.box_key_bits = kb;
             f.box_predicted = (gm == 2 && mode == 0) ? 1u : 0u;
-            // Global passes: enough that at most CM2_MAX_LOW_BITS index bits are left to the local finish, and
-            // enough that an average bucket (points / 2^(8 g)) stays well inside its LDS capacity; a frame that
-            // overflows anyway is handed back and v2_extra_passes adds a pass for the frames after it.
-            uint32_t g = 1 + (kb > CM2_MAX_LOW_BITS + 8 ? (kb - CM2_MAX_LOW_BITS - 1) / 8 : 0);
-            // (points: what the last frame kept after crop and masks, plus a quarter, when there was one)
+            // (points: what the last frame kept after crop and masks, plus a quarter, when there was one; a frame
+            // that overflows anyway is handed back and v2_extra_passes adds a pass for the frames after it)
             const uint64_t est = c->last_n_merged ? std::min<uint64_t>(c->n_in, c->last_n_merged + c->last_n_merged / 4) : c->n_in;
-            while (g < CM_MAX_PASSES && (est >> (8 * g)) > 256) ++g;
-            g += c->v2_extra_passes;
-            if (g > 1 && 8 * (g - 1) >= kb) g = 0;           // nothing left for the local finish to add
-            if (g >= 1 && g <= CM_MAX_PASSES) {
+            const uint32_t g = bucket_passes(kb, est, c->v2_extra_passes);
+            if (g) {
                 const uint32_t low = kb > 8 * g ? kb - 8 * g : 0;
                 if (!pre) return launch_bucket(c, gm, g, low, nullptr, nullptr, mode);
                 c->post_bucket = true; c->post_g = g; c->post_low = low;
+                // the outlier stage's own sort can use the bucket kernels as well: the crop box fixes its grid too
+                c->pre_bucket = gm_o == 1 && box_grid(p->crop_min, p->crop_max, inv_cell, &kb_o, f.cell_min_b, f.cell_div_b) &&
+                                static_cast<uint64_t>(f.cell_div_b[1]) * static_cast<uint64_t>(f.cell_div_b[2]) <= CM_ROW_TABLE_CAP;
+                f.cell_key_bits = kb_o; f._pad_cell = 0;
+                if (c->pre_bucket && c->pre_bucket_off) { --c->pre_bucket_off; c->pre_bucket = false; }
             }
         }
     }
@@ -629,11 +649,39 @@ int launch_classic(cm_ctx* c, const cm_params* p, int mode, int grid_mode, uint3
         if (!c->d_state_o) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_state_o), sizeof(CmFrameState)));
         const uint32_t passes_o = gm_o ? (kb_o + CM_RADIX_BITS - 1) / CM_RADIX_BITS : CM_MAX_PASSES;
         HIP_TRY(c, hipMemsetAsync(c->d_state_o, 0, sizeof(CmFrameState), st));
-        if (!gm_o) { prof_mark(c, "k_minmax"); cmk_minmax(st, c->d_frame, c->partials, n_partials, in); }
-        keys_and_sort(c->d_state_o, gm_o, 1, in, nullptr, passes_o);
+        const uint32_t g = c->pre_bucket ? bucket_passes(kb_o, c->n_in, 0) : 0;
+        if (g) {
+            // Bucket kernels on the radius grid: records (x, y, z, padded index) grouped by the high key bits in g
+            // passes, then sorted tile by tile in LDS and written back in order — what the general path's (key, index)
+            // sort + gather produce, in fewer passes over less data. A radius cell too full for a tile hands the
+            // frame back (CM_DEV_ERR_BUCKET_PRE).
+            { const int e = bucket_buffers(c); if (e != CM_OK) return e; }
+            const uint32_t low = kb_o > 8 * g ? kb_o - 8 * g : 0;
+            uint32_t* grp0 = c->grp + gstride * (c->frame_seq & 1u);
+            uint32_t* grp0_next = c->grp + gstride * ((c->frame_seq & 1u) ^ 1u);
+            ++c->frame_seq;
+            prof_mark(c, "k2_hist0(outlier)");
+            cmk2_hist0(st, c->d_frame, c->d_state_o, c->hist, grp0, grp0_next, c->grp + 2 * gstride, gw, static_cast<uint32_t>(gstride),
+                       c->tile_state, f.n_padded / 1024 + 2, c->records, 1, 0, low, g, nt, in, nullptr, 1);
+            for (uint32_t pass = 0; pass < g; ++pass) {
+                uint32_t* grp = pass == 0 ? grp0 : c->grp + 2 * gstride + static_cast<size_t>(pass - 1) * gw;
+                if (pass > 0) { prof_mark(c, "k2_hist"); cmk2_hist(st, c->d_state_o, c->dig, c->hist, grp, nt); }
+                if (big) { prof_mark(c, "k_gscan"); cmk_gscan(st, c->d_state_o, grp, c->totals, pass, n_groups); }
+                prof_mark(c, "k2_scatter(outlier)");
+                cmk2_scatter(st, pass == 0, c->d_frame, c->d_state_o, (pass & 1u) ? c->rec_a : c->rec_b, (pass & 1u) ? c->rec_b : c->rec_a,
+                             c->dig, c->hist, grp, big ? c->totals : nullptr, low + 8 * pass, pass + 1 < g ? low + 8 * (pass + 1) : 32u,
+                             nt, n_groups, f.n_padded, c->records, nt, 0, in, 1);
+            }
+            prof_mark(c, "k2_local(sort)");
+            cmk2_local_sort(st, c->d_frame, c->d_state_o, c->h_state_dev, ((g - 1) & 1u) ? c->rec_b : c->rec_a,
+                            (g & 1u) ? c->keys_b : c->keys_a, c->sorted_pts, low, f.n_padded);
+        } else {
+            if (!gm_o) { prof_mark(c, "k_minmax"); cmk_minmax(st, c->d_frame, c->partials, n_partials, in); }
+            keys_and_sort(c->d_state_o, gm_o, 1, in, nullptr, passes_o);
+        }
         prof_mark(c, "outlier_mask");
         cmk_outlier_mask(st, c->d_frame, c->d_state_o, c->keys_a, c->vals_a, c->keys_b, c->vals_b, c->sorted_pts,
-                         c->rows, out, f.n_padded, cls, c->merged_total + 8);
+                         c->rows, out, f.n_padded, cls, c->merged_total + 8, g != 0);
         return CM_OK;
     };
     const bool ground_outl = c->ground_on && mode == 0 && c->ground_outlier_radius > 0.0f;
@@ -740,12 +788,16 @@ int wait_frame(cm_ctx* c, cm_result* res) {
             // bucket did not fit LDS, or when a workgroup gave up waiting for its predecessors: the
             // classic path redoes it (the sensors' clouds are still in place) and the cause is dealt with.
             const CmFrameState& h0 = *c->h_state;
-            if (h0.outside || h0.err == CM_DEV_ERR_BUCKET || h0.err == CM_DEV_ERR_LOOKBACK) {
+            if (h0.outside || h0.err == CM_DEV_ERR_BUCKET || h0.err == CM_DEV_ERR_BUCKET_PRE || h0.err == CM_DEV_ERR_LOOKBACK) {
                 if (h0.outside) c->pred_ok = false;
                 if (h0.err == CM_DEV_ERR_BUCKET) {
                     if (c->v2_extra_passes < CM_MAX_PASSES) ++c->v2_extra_passes;
                     if (c->v2_good_frames < 8 && c->v2_retry_after < (1u << 20)) c->v2_retry_after *= 2;   // the retry failed at once
                     c->v2_good_frames = 0;
+                }
+                if (h0.err == CM_DEV_ERR_BUCKET_PRE) {        // a radius cell too full for a tile: more passes would not help
+                    c->pre_bucket_off = c->pre_bucket_backoff;
+                    if (c->pre_bucket_backoff < (1u << 20)) c->pre_bucket_backoff *= 2;
                 }
                 if (h0.err == CM_DEV_ERR_LOOKBACK) c->v2_off_frames = 0xFFFFFFFFu;
                 ++c->n_redone;
@@ -765,6 +817,7 @@ int wait_frame(cm_ctx* c, cm_result* res) {
                     c->frame.outlier_min_nb = prev.outlier_min_nb;
                     for (int a = 0; a < 3; ++a) { c->frame.ext_min[a] = prev.ext_min[a]; c->frame.ext_max[a] = prev.ext_max[a]; }
                     c->post_bucket = false;
+                    c->pre_bucket = false;
                     if (e == CM_OK && c->frame.n_padded)
                         e = launch_classic(c, &pr, c->last_mode, c->last_grid_mode, c->last_key_bits, c->last_outl, c->last_gm_o, c->last_kb_o);
                     else if (e == CM_OK)

@@ -75,6 +75,11 @@ struct CmFrameDev {
     int32_t box_div_b[3];
     uint32_t box_key_bits;
     uint32_t box_predicted;   // 1: the box is a prediction (check every point against it)
+    // ... and of the radius grid of the outlier stage over the crop box (cells 1.01 r wide), same set-up
+    int32_t cell_min_b[3];
+    int32_t cell_div_b[3];
+    uint32_t cell_key_bits;
+    uint32_t _pad_cell;
 };
 
 // Zone-wise ground removal (cm_kernels_ground.hip): per sensor up to 8 x-slabs, each with a z band.
@@ -124,6 +129,7 @@ struct CmFrameState {
 #define CM_DEV_ERR_UNSORTED 2u   // CmFrameState.err: the radix sort's output was not sorted
 #define CM_DEV_ERR_LOOKBACK 3u   // ... a workgroup waited too long for its predecessors' counts
 #define CM_DEV_ERR_BUCKET 4u     // ... a bucket did not fit the local finish's LDS capacity
+#define CM_DEV_ERR_BUCKET_PRE 5u // ... the same in the outlier stage's sort (a radius cell with thousands of points)
 #define CM_DEV_OUTLIER_GRID 3   // the radius grid of the outlier stage does not fit (rows or 32-bit index)
 
 #define CM_ROW_TABLE_CAP (1u << 22)   // rows (y,z cell pairs) of the outlier stage's candidate grid

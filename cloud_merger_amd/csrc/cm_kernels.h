@@ -15,7 +15,8 @@ void cmk_keys(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* k
 // Outlier stage after the sort by the radius grid: gather into sorted order, row table, neighbour counts -> mask.
 void cmk_outlier_mask(hipStream_t s, const CmFrameDev* fd, const CmFrameState* st, const uint32_t* keys_a,
                       const uint32_t* vals_a, const uint32_t* keys_b, const uint32_t* vals_b, void* sorted_pts,
-                      void* rows, unsigned char* mask, uint32_t n_padded, const unsigned char* cls, uint32_t* pend_n);
+                      void* rows, unsigned char* mask, uint32_t n_padded, const unsigned char* cls, uint32_t* pend_n,
+                      bool already_gathered = false);
 void cmk_hist(hipStream_t s, const CmFrameState* st, const uint32_t* keys, uint32_t* hist, uint32_t* grp,
               uint32_t pass, uint32_t n_tiles);
 void cmk_gscan(hipStream_t s, const CmFrameState* st, uint32_t* grp, uint32_t* totals, uint32_t pass,
@@ -47,16 +48,19 @@ void cmk2_hist0(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t*
                 uint32_t* grp_clear_a, uint32_t* grp_clear_b, uint32_t n_group_words, uint32_t n_clear_a_words,
                 unsigned long long* tile_state, uint32_t n_tile_state, float* records, int grid_mode, int check_box,
                 uint32_t shift0, uint32_t n_global_passes, uint32_t n_tiles, const unsigned char* mask,
-                const CmFrameState* st_outlier);
+                const CmFrameState* st_outlier, int use_cell = 0);
 void cmk2_hist(hipStream_t s, const CmFrameState* st, const unsigned char* dig, uint32_t* hist, uint32_t* grp,
                uint32_t n_tiles);
 void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, CmFrameState* st, const void* rec_in, void* rec_out,
                   unsigned char* dig_out, const uint32_t* hist, const uint32_t* grp, const uint32_t* totals,
                   uint32_t shift, uint32_t next_shift, uint32_t n_tiles, uint32_t n_groups, uint32_t n_padded,
-                  const float* records, uint32_t n_records, int fold, const unsigned char* mask);
+                  const float* records, uint32_t n_records, int fold, const unsigned char* mask, int use_cell = 0);
 void cmk2_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next, uint32_t* host_state,
                 const void* rec, unsigned long long* tile_state, uint32_t* ticket, void* out, uint32_t* out_key,
                 uint32_t* out_cnt, void* partial_out, uint32_t low_bits, uint32_t n_padded);
+// outlier stage: the records (x, y, z, padded index) fully sorted by radius-grid key, keys beside them
+void cmk2_local_sort(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* host_state, const void* rec,
+                     uint32_t* keys_sorted, void* recs_sorted, uint32_t low_bits, uint32_t n_padded);
 
 // ---- zone-wise ground removal (cm_kernels_ground.hip) ------------------------------------------
 void cmkg_setup(hipStream_t s, const CmGroundDev& g, CmGroundDev* d_ground);

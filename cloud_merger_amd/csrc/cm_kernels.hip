@@ -1266,9 +1266,11 @@ void cmk_keys(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* k
 }
 void cmk_outlier_mask(hipStream_t s, const CmFrameDev* fd, const CmFrameState* st, const uint32_t* keys_a,
                       const uint32_t* vals_a, const uint32_t* keys_b, const uint32_t* vals_b, void* sorted_pts,
-                      void* rows, unsigned char* mask, uint32_t n_padded, const unsigned char* cls, uint32_t* pend_n) {
+                      void* rows, unsigned char* mask, uint32_t n_padded, const unsigned char* cls, uint32_t* pend_n,
+                      bool already_gathered) {
     const uint32_t blocks = (n_padded + CM_BLOCK * 4 - 1) / (CM_BLOCK * 4);
-    CM_LAUNCH(k_gather_sorted, blocks, CM_BLOCK, s, fd, st, vals_a, vals_b, reinterpret_cast<float4*>(sorted_pts));
+    if (!already_gathered)
+        CM_LAUNCH(k_gather_sorted, blocks, CM_BLOCK, s, fd, st, vals_a, vals_b, reinterpret_cast<float4*>(sorted_pts));
     CM_LAUNCH(k_row_clear, 1024, CM_BLOCK, s, st, reinterpret_cast<uint2*>(rows));
     CM_LAUNCH(k_row_table, blocks, CM_BLOCK, s, st, keys_a, keys_b, reinterpret_cast<uint2*>(rows));
     // pending list: point numbers in the keys buffer the sort did not end in, their counts in a vals buffer

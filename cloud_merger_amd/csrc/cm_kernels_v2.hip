@@ -70,11 +70,13 @@ struct BoxGrid {
     uint32_t mul1, mul2;
 };
 
-__device__ __forceinline__ BoxGrid box_grid_of(const CmFrameDev* __restrict__ fd) {
+// use_cell: the radius grid of the outlier stage instead of the voxel grid
+__device__ __forceinline__ BoxGrid box_grid_of(const CmFrameDev* __restrict__ fd, int use_cell = 0) {
     BoxGrid b;
-    const int32_t* min_b = fd->box_min_b;
-    const int32_t* div_b = fd->box_div_b;
-    b.inv0 = fd->inv_leaf[0]; b.inv1 = fd->inv_leaf[1]; b.inv2 = fd->inv_leaf[2];
+    const int32_t* min_b = use_cell ? fd->cell_min_b : fd->box_min_b;
+    const int32_t* div_b = use_cell ? fd->cell_div_b : fd->box_div_b;
+    const float* inv = use_cell ? fd->inv_cell : fd->inv_leaf;
+    b.inv0 = inv[0]; b.inv1 = inv[1]; b.inv2 = inv[2];
     b.fb0 = static_cast<float>(min_b[0]); b.fb1 = static_cast<float>(min_b[1]); b.fb2 = static_cast<float>(min_b[2]);
     b.d0 = div_b[0]; b.d1 = div_b[1]; b.d2 = div_b[2];
     b.mul1 = static_cast<uint32_t>(div_b[0]);
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(CM2_BLOCK) void k2_hist0(const CmFrameDev* __restri
                                                       float* __restrict__ records,
                                                       int grid_mode, int check_box, uint32_t shift0, uint32_t n_global_passes,
                                                       const unsigned char* __restrict__ mask,
-                                                      const CmFrameState* __restrict__ st_outlier) {
+                                                      const CmFrameState* __restrict__ st_outlier, int use_cell) {
     __shared__ uint32_t lh[CM_RADIX];
     __shared__ float s_mm[CM2_WAVES][6];
     __shared__ uint32_t s_cnt[CM2_WAVES];
@@ -143,13 +145,14 @@ __global__ __launch_bounds__(CM2_BLOCK) void k2_hist0(const CmFrameDev* __restri
         for (int a = 0; a < 3; ++a) {
             st->min_p[a] = grid_mode == 2 ? fd->ext_min[a] : fd->crop_min[a];
             st->max_p[a] = grid_mode == 2 ? fd->ext_max[a] : fd->crop_max[a];
-            st->min_b[a] = fd->box_min_b[a]; st->max_b[a] = fd->box_min_b[a] + fd->box_div_b[a] - 1;
-            st->div_b[a] = fd->box_div_b[a];
+            const int32_t mb = use_cell ? fd->cell_min_b[a] : fd->box_min_b[a], db = use_cell ? fd->cell_div_b[a] : fd->box_div_b[a];
+            st->min_b[a] = mb; st->max_b[a] = mb + db - 1;
+            st->div_b[a] = db;
         }
-        st->key_bits = fd->box_key_bits;
+        st->key_bits = use_cell ? fd->cell_key_bits : fd->box_key_bits;
         st->n_passes = n_global_passes;
     }
-    const BoxGrid b = box_grid_of(fd);
+    const BoxGrid b = box_grid_of(fd, use_cell);
     const bool predicted = check_box != 0;        // the box is a prediction: verify every point, record the true bounds
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 3) void k2_scatter(const CmFrameDev* __r
                                                            uint32_t n_groups, uint32_t n_padded,
                                                            const float* __restrict__ records,
                                                            uint32_t n_records, int fold,
-                                                           const unsigned char* __restrict__ mask) {
+                                                           const unsigned char* __restrict__ mask, int use_cell) {
     __shared__ float4 srec[CM_TILE / 2];                // staging in two halves: 41 KB per workgroup, three per CU
     __shared__ uint32_t whist[CM2_WAVES][CM_RADIX];
     __shared__ uint32_t gofs[CM_RADIX];
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 3) void k2_scatter(const CmFrameDev* __r
         const uint32_t per = gridDim.x / 8;              // contiguous tile range per XCD (see k_scatter)
         if (blockIdx.x < per * 8) tile = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
     }
-    const BoxGrid b = box_grid_of(fd);
+    const BoxGrid b = box_grid_of(fd, use_cell);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t first = tile * CM_TILE + w * (64 * CM2_ITEMS) + lane;
 
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 3) void k2_scatter(const CmFrameDev* __r
             rec[r].x = xf_row(m[0], m[1], m[2], m[3], p[r].x, p[r].y, p[r].z);
             rec[r].y = xf_row(m[4], m[5], m[6], m[7], p[r].x, p[r].y, p[r].z);
             rec[r].z = xf_row(m[8], m[9], m[10], m[11], p[r].x, p[r].y, p[r].z);
-            rec[r].w = all_fields ? p[r].i : 0.f;
+            rec[r].w = use_cell ? __uint_as_float(first + r * 64) : (all_fields ? p[r].i : 0.f);   // outlier stage: the point's padded index rides along
             bool in = false;
             key[r] = 0;
             if (point_valid(rec[r].x, rec[r].y, rec[r].z, crop, fd->crop_min, fd->crop_max) &&
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 3) void k2_scatter(const CmFrameDev* __r
 #define CM2_FLAG_AGG (1ull << 32)
 #define CM2_FLAG_PREFIX (2ull << 32)
 
-template <int LT, int LCAP, int LBLOCK>
+template <int LT, int LCAP, int LBLOCK, bool WRITEBACK>
 __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const CmFrameDev* __restrict__ fd,
                                                        CmFrameState* __restrict__ st,
                                                        CmFrameState* __restrict__ st_next,
@@ -480,7 +483,11 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
                                                        uint32_t* __restrict__ out_key,
                                                        uint32_t* __restrict__ out_cnt,
                                                        float4* __restrict__ partial_out,
-                                                       uint32_t low_bits) {
+                                                       uint32_t low_bits,
+                                                       uint32_t* __restrict__ keys_sorted, float4* __restrict__ recs_sorted,
+                                                       int use_cell) {
+    // WRITEBACK (outlier stage): no voxels — the tile's records and keys go back to HBM in key order; since the
+    // tiles' owned ranges partition the array in order, that leaves the whole array sorted.
     constexpr int LWAVES = LBLOCK / 64, LITEMS = (LCAP + LBLOCK - 1) / LBLOCK, EXT0 = LBLOCK < 256 ? LBLOCK : 256;
     constexpr int BINS = 1024, HWORDS = BINS / 2;          // two 16-bit counters per LDS word
     static_assert(LT == 4 * LBLOCK && LCAP <= 0xFFFF && HWORDS <= LBLOCK && LWAVES * HWORDS * 2 >= LCAP, "tile geometry");
@@ -512,8 +519,8 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
     // (look-back below) only for tiles with smaller tickets, i.e. for workgroups that are already running —
     // whatever order and placement the hardware dispatches workgroups in (several XCDs, other streams, other
     // processes on the same GPU). The n_lt workgroups that stay draw the tickets 0 .. n_lt-1 between them.
-    if (threadIdx.x == 0) s_a = atomicAdd(ticket, 1u);
-    const BoxGrid b0 = box_grid_of(fd);
+    if (threadIdx.x == 0) s_a = WRITEBACK ? blockIdx.x : atomicAdd(ticket, 1u);     // nobody waits for anybody when writing back
+    const BoxGrid b0 = box_grid_of(fd, use_cell);
     __syncthreads();
     const uint32_t tile = s_a;
     __syncthreads();
@@ -585,7 +592,7 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
         }
     }
     const uint32_t m = (a == 0xFFFFFFFFu || too_big) ? 0u : nom + ext - a;
-    if (too_big && threadIdx.x == 0) host_state[offsetof(CmFrameState, err) / 4] = CM_DEV_ERR_BUCKET;
+    if (too_big && threadIdx.x == 0) host_state[offsetof(CmFrameState, err) / 4] = WRITEBACK ? CM_DEV_ERR_BUCKET_PRE : CM_DEV_ERR_BUCKET;
 
     // ---- sort the owned slots [a, a+m) by key: LSD over the bits in which the keys of this tile can
     // differ, up to 10 per pass, stable. Only the slot numbers move (si); a pass reads its digit
@@ -659,6 +666,18 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
         }
     }
 
+    if (WRITEBACK) {
+        const uint32_t rounds_w = (m + LBLOCK - 1) / LBLOCK;
+        for (uint32_t r = 0; r < rounds_w; ++r) {
+            const uint32_t e = r * LBLOCK + threadIdx.x;
+            if (e < m) {
+                const uint32_t slot = si[e];
+                keys_sorted[base + a + e] = sk[slot];
+                recs_sorted[base + a + e] = rec[base + slot];
+            }
+        }
+        return;
+    }
     // ---- voxels of the tile: a head is a sorted item whose key differs from the one before it.
     // hpos[v] = sorted position of voxel v's first point (the counters' LDS is free now).
     uint32_t heads = 0, nh = 0;
@@ -802,10 +821,10 @@ void cmk2_hist0(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t*
                 uint32_t* grp_clear_a, uint32_t* grp_clear_b, uint32_t n_group_words, uint32_t n_clear_a_words,
                 unsigned long long* tile_state, uint32_t n_tile_state, float* records, int grid_mode, int check_box,
                 uint32_t shift0, uint32_t n_global_passes, uint32_t n_tiles, const unsigned char* mask,
-                const CmFrameState* st_outlier) {
+                const CmFrameState* st_outlier, int use_cell) {
     hipLaunchKernelGGL(k2_hist0, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, st, hist, grp_acc, grp_clear_a, grp_clear_b,
                        n_group_words, n_clear_a_words, tile_state, n_tile_state, records, grid_mode, check_box, shift0,
-                       n_global_passes, mask, st_outlier);
+                       n_global_passes, mask, st_outlier, use_cell);
 }
 void cmk2_hist(hipStream_t s, const CmFrameState* st, const unsigned char* dig, uint32_t* hist, uint32_t* grp,
                uint32_t n_tiles) {
@@ -814,21 +833,27 @@ void cmk2_hist(hipStream_t s, const CmFrameState* st, const unsigned char* dig, 
 void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, CmFrameState* st, const void* rec_in, void* rec_out,
                   unsigned char* dig_out, const uint32_t* hist, const uint32_t* grp, const uint32_t* totals,
                   uint32_t shift, uint32_t next_shift, uint32_t n_tiles, uint32_t n_groups, uint32_t n_padded,
-                  const float* records, uint32_t n_records, int fold, const unsigned char* mask) {
+                  const float* records, uint32_t n_records, int fold, const unsigned char* mask, int use_cell) {
     const float4* in = reinterpret_cast<const float4*>(rec_in);
     float4* o = reinterpret_cast<float4*>(rec_out);
     if (first)
         hipLaunchKernelGGL(k2_scatter<true>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, st, in, o, dig_out, hist, grp,
-                           totals, shift, next_shift, n_groups, n_padded, records, n_records, fold, mask);
+                           totals, shift, next_shift, n_groups, n_padded, records, n_records, fold, mask, use_cell);
     else
         hipLaunchKernelGGL(k2_scatter<false>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, st, in, o, dig_out, hist, grp,
-                           totals, shift, next_shift, n_groups, n_padded, records, n_records, fold, mask);
+                           totals, shift, next_shift, n_groups, n_padded, records, n_records, fold, mask, use_cell);
 }
 void cmk2_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next, uint32_t* host_state,
                 const void* rec, unsigned long long* tile_state, uint32_t* ticket, void* out, uint32_t* out_key,
                 uint32_t* out_cnt, void* partial_out, uint32_t low_bits, uint32_t n_padded) {
     // 2048-record tiles, room for 4096 (bucket tails up to 2048 records), 512 threads: 42 KB of LDS, three per CU
-    hipLaunchKernelGGL((k2_local<2048, 4096, 512>), dim3(n_padded / 2048), dim3(512), 0, s, fd, st, st_next, host_state,
+    hipLaunchKernelGGL((k2_local<2048, 4096, 512, false>), dim3(n_padded / 2048), dim3(512), 0, s, fd, st, st_next, host_state,
                        reinterpret_cast<const float4*>(rec), tile_state, ticket, reinterpret_cast<float4*>(out), out_key,
-                       out_cnt, reinterpret_cast<float4*>(partial_out), low_bits);
+                       out_cnt, reinterpret_cast<float4*>(partial_out), low_bits, nullptr, nullptr, 0);
+}
+void cmk2_local_sort(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* host_state, const void* rec,
+                     uint32_t* keys_sorted, void* recs_sorted, uint32_t low_bits, uint32_t n_padded) {
+    hipLaunchKernelGGL((k2_local<2048, 4096, 512, true>), dim3(n_padded / 2048), dim3(512), 0, s, fd, st, nullptr, host_state,
+                       reinterpret_cast<const float4*>(rec), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, low_bits,
+                       keys_sorted, reinterpret_cast<float4*>(recs_sorted), 1);
 }

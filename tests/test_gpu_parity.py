@@ -419,6 +419,44 @@ def test_outlier_removal_reference_parameters(sort_path):
     assert bool(g["res"].path_flags & BUCKET) == (sort_path == "auto" and bool(g["res"].path_flags & 1))     # crop box: the voxel stage after the filter takes the bucket path
 
 
+@pytest.mark.parametrize("radius,min_nb,n", [(0.15, 1, 60_000), (0.05, 1, 150_000), (0.4, 4, 30_000), (2.0, 40, 9_000)])
+def test_outlier_removal_in_crop_box(radius, min_nb, n):
+    """Crop box + outlier filter: on the default path the filter's own sort runs on the bucket kernels over
+    the radius grid (few key bits for a wide radius, many for a narrow one); the classic path sorts (key, index)
+    pairs. Both must keep exactly the oracle's points."""
+    sensors, params = synth.config2(n_per_sensor=n, min_pts=0)
+    params.crop_min, params.crop_max = (-30.0, -25.0, -3.0), (35.0, 30.0, 4.0)
+    params.outlier_radius, params.outlier_min_neighbors = radius, min_nb
+    g, rep = check_against_oracle(sensors, params, exact_small_runs=True)
+    assert 0 < g["res"].n_merged < g["res"].n_in
+    assert not g["res"].path_flags & REDONE
+
+
+def test_outlier_stage_hands_back_an_overfull_radius_cell():
+    """A radius cell holding more points than a tile of the bucket sort can take (a wall right in front of a
+    sensor): the frame is handed back and redone with the general sort, the result is the oracle's, and the
+    following frames do not try again at once."""
+    rng = np.random.default_rng(5)
+    dense = rng.uniform(0.0, 0.27, (9_000, 3)) + np.array([0.92, 0.92, 0.92])     # inside the radius cell [0.909, 1.212)^3, ~300 voxels
+    sparse = rng.uniform(-20, 20, (40_000, 3))
+    xyz = np.concatenate([dense, sparse]).astype(np.float32)
+    s = [xyzi_cloud(xyz, np.arange(len(xyz), dtype=np.float32))]
+    p = MergeParams(leaf=(0.05,) * 3, min_points_per_voxel=0, outlier_radius=0.3, outlier_min_neighbors=2,
+                    crop_min=(-25, -25, -25), crop_max=(25, 25, 25))
+    st, merged_ref, ref, rep = oracle.merge_voxelize(s, p, stable=True)
+    with capi.CloudMerger(max_points_total=len(xyz), max_sensors=1, flags=capi.FLAG_OCCUPANCY) as cm:
+        flags = []
+        for _ in range(3):
+            cm.submit_all(s)
+            res = cm.merge_voxelize(p)
+            assert res.status == capi.OK and res.n_out == rep.n_out and res.n_merged == rep.n_merged
+            cells, counts = cm.cells(res.n_out)
+            assert np.array_equal(cells, rep.cells) and np.array_equal(counts, rep.counts)
+            flags.append(res.path_flags)
+    if flags[0] & BUCKET or flags[0] & REDONE:             # default path on an LDS-ranking device
+        assert flags[0] & REDONE and not flags[1] & REDONE and not flags[2] & REDONE
+
+
 def test_outlier_removal_small_known_case():
     xyz = np.array([[0, 0, 0], [0.1, 0, 0], [5, 0, 0], [9, 9, 9], [9.05, 9, 9], [np.nan, 0, 0]], np.float32)
     s = [xyzi_cloud(xyz, np.arange(6, dtype=np.float32), is_dense=False)]
