@@ -30,12 +30,7 @@
 #define CM2_BLOCK 512         // threads per workgroup in the record passes (8 wave64, 8 points each)
 #define CM2_WAVES 8
 #define CM2_ITEMS 8
-#define CM2_LBLOCK 1024       // threads per workgroup in the local finish (16 wave64)
-#define CM2_LWAVES 16
-#define CM2_LT 4096           // nominal records per local tile
-#define CM2_LCAP 6144         // LDS capacity in records: a tile owns the buckets that START in it, so it
-                              // can run past its nominal end by one bucket tail (<= CM2_LCAP - CM2_LT)
-#define CM2_LITEMS 6          // CM2_LCAP / CM2_LBLOCK
+// (the local finish's geometry — 2048-record tiles, room for 4096, 512 threads — is fixed where it is launched: cmk2_local)
 #define CM2_MAX_LOW_BITS 14   // key bits left to the local finish when the global passes allow it
 
 // Point layouts the loaders special-case.
