@@ -116,7 +116,7 @@ struct cm_ctx {
     bool pred_ok = false;                // a box predicted from an earlier frame's bounds
     float pred_min[3] = {0, 0, 0}, pred_max[3] = {0, 0, 0};
     uint32_t v2_extra_passes = 0;        // buckets overflowed LDS: sort more bits globally
-    uint32_t v2_good_frames = 0;         // bucket-path frames since the last overflow
+    uint32_t v2_good_frames = 0;         // frames since the last overflow (on whichever path they ran)
     uint32_t v2_retry_after = 256;       // ... after this many, try one global pass fewer again (doubles on failure)
     uint32_t v2_off_frames = 0;          // ... or give the path a rest
     uint32_t pre_bucket_off = 0;         // frames for which the outlier stage sorts with the general kernels (a bucket overflowed)
@@ -830,7 +830,8 @@ int wait_frame(cm_ctx* c, cm_result* res) {
                 r.n_in = c->n_in;
             }
         }
-        if (c->last_v2 && c->v2_extra_passes && ++c->v2_good_frames >= c->v2_retry_after) {
+        // (counted on the general path too: extra passes can add up to "no bucket path at all", and that must not be for ever)
+        if (!redone && c->v2_extra_passes && ++c->v2_good_frames >= c->v2_retry_after) {
             --c->v2_extra_passes;                          // the scene may have thinned out: try with less global sorting
             c->v2_good_frames = 0;
         }
