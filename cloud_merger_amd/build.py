@@ -43,6 +43,8 @@ def build(force=False, save_temps=False, verbose=False):
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [hipcc()] + FLAGS + ["-I", CSRC, "-o", LIB_PATH]
+    if os.environ.get("CM_PHASE_TIMING") == "1":       # experiment build: scripts/phase_times.py (never the shipped one)
+        cmd += ["-DCM_PHASE_TIMING"]
     if save_temps:
         tmp = os.path.join(HERE, "build_tmp")
         os.makedirs(tmp, exist_ok=True)

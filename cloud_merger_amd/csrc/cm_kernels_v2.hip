@@ -471,6 +471,16 @@ __global__ __launch_bounds__(CM2_BLOCK, 3) void k2_scatter(const CmFrameDev* __r
 #define CM2_FLAG_AGG (1ull << 32)
 #define CM2_FLAG_PREFIX (2ull << 32)
 
+// Phase timing of the local finish (scripts/phase_times.py; build with CM_PHASE_TIMING=1): thread 0 of every
+// workgroup stores the 100 MHz ticks between phase boundaries. Compiled out of the product build.
+#ifdef CM_PHASE_TIMING
+__device__ unsigned long long g_phase[4096 * 16];
+#define PH_START() long long t0_ = wall_clock64()
+#define PH(k) do { if (threadIdx.x == 0) { const long long t1_ = wall_clock64(); g_phase[(blockIdx.x & 4095) * 16 + (k)] = (unsigned long long)(t1_ - t0_); t0_ = t1_; } } while (0)
+#else
+#define PH_START() do {} while (0)
+#define PH(k) do {} while (0)
+#endif
 template <int LT, int LCAP, int LBLOCK, bool WRITEBACK>
 __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const CmFrameDev* __restrict__ fd,
                                                        CmFrameState* __restrict__ st,
@@ -499,6 +509,7 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
     __shared__ uint32_t s_a, s_keyprev, s_off;
     uint16_t* hpos = reinterpret_cast<uint16_t*>(&whist[0][0]);
 
+    PH_START();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (blockIdx.x == 0 && st_next && threadIdx.x < sizeof(CmFrameState) / 4)
         reinterpret_cast<uint32_t*>(st_next)[threadIdx.x] = 0;
@@ -525,6 +536,7 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
     const uint32_t tile = s_a;
     __syncthreads();
     const BoxGrid b = b0;
+    PH(0);
     const uint32_t L = low_bits;
     // partial_out: this GPU's share of a fused cloud — per-voxel sums and counts, no threshold, no division (§6)
     const uint32_t min_pts = (!partial_out && fd->min_pts > 1) ? fd->min_pts : 1u;
@@ -553,6 +565,7 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
         if (threadIdx.x == 0) { s_keyprev = base > 0 ? key_of(b, pv) : 0u; s_a = 0xFFFFFFFFu; }
     }
     __syncthreads();
+    PH(1);
 
     // ---- a: first bucket start in the nominal tile
     {
@@ -594,6 +607,7 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
     const uint32_t m = (a == 0xFFFFFFFFu || too_big) ? 0u : nom + ext - a;
     if (too_big && threadIdx.x == 0) host_state[offsetof(CmFrameState, err) / 4] = WRITEBACK ? CM_DEV_ERR_BUCKET_PRE : CM_DEV_ERR_BUCKET;
 
+    PH(2);
     // ---- sort the owned slots [a, a+m) by key: LSD over the bits in which the keys of this tile can
     // differ, up to 10 per pass, stable. Only the slot numbers move (si); a pass reads its digit
     // through the slot. Ranking: returning LDS adds on per-wave counters (lane order, see k_scatter).
@@ -666,6 +680,7 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
         }
     }
 
+    PH(3);
     if (WRITEBACK) {
         const uint32_t rounds_w = (m + LBLOCK - 1) / LBLOCK;
         for (uint32_t r = 0; r < rounds_w; ++r) {
@@ -704,6 +719,7 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
     }
     __syncthreads();
 
+    PH(4);
     // ---- kept voxels (A.4 step 7: at least min_pts points), published at once for the look-back
     // Thread t takes voxels [t * pv, (t + 1) * pv): a wave covers 64 * pv consecutive voxels (similar run
     // lengths), and the kept ones get consecutive output slots from one scan.
@@ -731,9 +747,13 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
         const unsigned long long v = (tile == 0 ? CM2_FLAG_PREFIX : CM2_FLAG_AGG) | c_t;
         __hip_atomic_store(&tile_state[tile], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    PH(5);
     // ---- output offset: kept voxels of every earlier tile (decoupled look-back). The last wave does
     // it while the others add up their voxels: it has the fewest voxels (often none), and what it waits for —
     // the counts of the tiles before this one — is being published in the meantime.
+#ifdef CM_PHASE_TIMING
+    const long long tw0_ = wall_clock64();
+#endif
     if (w == LWAVES - 1) {
         uint32_t excl = 0;
         bool timed_out = false, done = false;
@@ -773,6 +793,9 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
             s_off = excl;
         }
         if (__ballot(timed_out) && lane == 0) host_state[offsetof(CmFrameState, err) / 4] = CM_DEV_ERR_LOOKBACK;
+#ifdef CM_PHASE_TIMING
+        if (lane == 0) g_phase[(blockIdx.x & 4095) * 16 + 9] = (unsigned long long)(wall_clock64() - tw0_);
+#endif
     }
     // ---- centroid sums: one lane per kept voxel adds its points in sorted (= stable) order, the
     // order pcl::VoxelGrid itself adds them in (A.4 step 6).
@@ -791,7 +814,12 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
         }
     }
 
+#ifdef CM_PHASE_TIMING
+    if (lane == 0 && w >= 1 && w <= 6) g_phase[(blockIdx.x & 4095) * 16 + 9 + w] = (unsigned long long)(wall_clock64() - tw0_);   // 10..15: waves 1..6
+#endif
+    PH(6);
     __syncthreads();
+    PH(7);
     const uint32_t tile_off = s_off;
     if (tile == n_lt - 1) report_state(host_state, st, CM_DEV_OK, tile_off + c_t, true);
 
@@ -813,9 +841,16 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
             ++slot;
         }
     }
+    PH(8);
 }
 
 }  // namespace
+#ifdef CM_PHASE_TIMING
+extern "C" __attribute__((visibility("default"))) void cm_debug_phases(unsigned long long* out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 16 * 4096);
+    if (reset) { void* p_; (void)hipGetSymbolAddress(&p_, HIP_SYMBOL(g_phase)); (void)hipMemset(p_, 0, sizeof(unsigned long long) * 16 * 4096); }
+}
+#endif
 
 void cmk2_hist0(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* hist, uint32_t* grp_acc,
                 uint32_t* grp_clear_a, uint32_t* grp_clear_b, uint32_t n_group_words, uint32_t n_clear_a_words,
