@@ -527,6 +527,7 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
     c->last_mode = mode;
 
     if (f.n_padded == 0) {                             // every submitted cloud is empty
+        c->frame_had_ground = c->ground_on && mode == 0;   // ... so are the ground cloud and every slab (no stale planes)
         c->pending = true;
         c->pending_trivial = true;
         return CM_OK;
@@ -1255,6 +1256,10 @@ int cm_ground_planes(cm_ctx* c, cm_ground_plane* planes, uint32_t capacity) {
     if (!c->have_result || !c->frame_had_ground) return fail(c, CM_BAD_ARG, "the last frame ran without ground removal");
     static_assert(sizeof(cm_ground_plane) == sizeof(CmGroundPlaneDev), "plane record layout");
     const uint32_t n = std::min<uint32_t>(capacity, CM_DEV_MAX_SENSORS * CM_DEV_MAX_ZONES);
+    if (c->frame.n_padded == 0) {                      // an empty frame: no band points anywhere
+        std::memset(planes, 0, static_cast<size_t>(n) * sizeof(cm_ground_plane));
+        return CM_OK;
+    }
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(planes, c->d_planes, static_cast<size_t>(n) * sizeof(cm_ground_plane), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -177,7 +177,8 @@ __device__ __forceinline__ bool plane_from_3(const float4& p0, const float4& p1,
     float nx = __fsub_rn(__fmul_rn(ay, bz), __fmul_rn(az, by));
     float ny = __fsub_rn(__fmul_rn(az, bx), __fmul_rn(ax, bz));
     float nz = __fsub_rn(__fmul_rn(ax, by), __fmul_rn(ay, bx));
-    const float len = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
+    // (__builtin_sqrtf: the correctly rounded square root; HIP's __fsqrt_rn is the 1-ulp native instruction)
+    const float len = __builtin_sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
     if (!(len > 0.0f)) return false;
     nx = __fdiv_rn(nx, len); ny = __fdiv_rn(ny, len); nz = __fdiv_rn(nz, len);
     pl[0] = nx; pl[1] = ny; pl[2] = nz;

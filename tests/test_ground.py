@@ -121,6 +121,38 @@ def test_four_sensors_with_poses_keep_all_slab_and_gaps():
     check(sensors, zones, params)
 
 
+def test_sample_planes_without_refit_are_bit_exact():
+    """optimize_coefficients off: the reported plane is the best sample's own fp32 plane (cross product, square
+    root, divisions — PCL's operation order), so it must equal the oracle's bit for bit, slab after slab."""
+    rng = np.random.default_rng(31)
+    sensors = [xyzi_cloud(scene(rng, 30_000, tilt=0.013 * (s + 1), ground_sigma=0.04), rng.uniform(0, 255, 30_000)) for s in range(6)]
+    params = MergeParams(leaf=(0.1,) * 3, min_points_per_voxel=0, **ROI)
+    n_planes = 0
+    for it, iters in enumerate((1, 3, 25)):
+        gp = dict(GP, optimize=False, max_iterations=iters, threshold=0.05, seed=99 + it)
+        g, planes = check(sensors, [FRONT] * 6, params, gp)
+        for s, pls in enumerate(planes):
+            for k, pl in enumerate(pls):
+                if pl is not None and pl.found:
+                    n_planes += 1
+                    got = np.array(g["planes"][s * 8 + k].plane, np.float32)
+                    assert same_bits(got, np.array(pl.plane, np.float32)), (iters, s, k, got, pl.plane)
+    assert n_planes >= 60
+
+
+def test_empty_frame_after_a_ground_frame_reports_no_planes():
+    rng = np.random.default_rng(33)
+    full = [xyzi_cloud(scene(rng, 20_000), rng.uniform(0, 255, 20_000))]
+    empty = [xyzi_cloud(np.zeros((0, 3), np.float32), np.zeros(0, np.float32))]
+    params = MergeParams(leaf=(0.1,) * 3, min_points_per_voxel=0, **ROI)
+    with capi.CloudMerger(max_points_total=20_000, max_sensors=1, flags=capi.FLAG_OCCUPANCY) as cm:
+        g = run(full, [FRONT], params, GP, cm=cm)
+        assert any(p.found for p in g["planes"])
+        g = run(empty, [FRONT], params, GP, cm=cm)
+        assert g["res"].status == capi.EMPTY_INPUT and len(g["ground"]) == 0 and len(g["merged"]) == 0
+        assert not any(p.found or p.band_points or p.inliers for p in g["planes"])
+
+
 def test_band_outlier_filter_per_slab():
     """removeGround's outlierRemoval(:119): of a slab's band points that are not ground, those without a neighbour
     within 0.15 m (in the same slab's set) go. Sparse clutter in the band makes many of them lonely; two points
