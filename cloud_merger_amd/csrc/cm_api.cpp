@@ -81,6 +81,8 @@ struct cm_ctx {
     std::atomic<bool> in_flight{false};
     bool pending = false;                // an enqueued frame has not been waited for
     bool pending_trivial = false;        // ... and it had no kernels (nothing submitted)
+    bool trivial_grid = false;           // ... but, as an empty share of a fused cloud, it has the shared grid
+    float trivial_box[6] = {0, 0, 0, 0, 0, 0};
     CmFrameDev frame;                    // descriptor of the last enqueued frame
     bool from_crop = false;
     uint64_t n_in = 0;
@@ -528,6 +530,18 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
 
     if (f.n_padded == 0) {                             // every submitted cloud is empty
         c->frame_had_ground = c->ground_on && mode == 0;   // ... so are the ground cloud and every slab (no stale planes)
+        c->trivial_grid = false;
+        if (mode == 1) {
+            // An empty share of a fused cloud still belongs to the shared grid: cm_merge_tables on this context
+            // reports and decodes cells with it.
+            const float* lo = grid_mode == 1 ? p->crop_min : bounds;
+            const float* hi = grid_mode == 1 ? p->crop_max : bounds + 3;
+            uint32_t kb = 0;
+            if (box_grid(lo, hi, inv_leaf, &kb, c->cell_min_b, c->cell_div_b)) {
+                c->trivial_grid = true;
+                for (int a = 0; a < 3; ++a) { c->trivial_box[a] = lo[a]; c->trivial_box[3 + a] = hi[a]; }
+            }
+        }
         c->pending = true;
         c->pending_trivial = true;
         return CM_OK;
@@ -780,6 +794,13 @@ int wait_frame(cm_ctx* c, cm_result* res) {
     r.n_in = c->n_in;
     if (c->pending_trivial) {
         r.status = CM_EMPTY_INPUT;
+        if (c->last_mode == 1 && c->trivial_grid) {
+            r.bounds_from_crop = 1;
+            for (int a = 0; a < 3; ++a) {
+                r.min_b[a] = c->cell_min_b[a]; r.div_b[a] = c->cell_div_b[a]; r.max_b[a] = r.min_b[a] + r.div_b[a] - 1;
+                r.min_p[a] = c->trivial_box[a]; r.max_p[a] = c->trivial_box[3 + a];
+            }
+        }
     } else {
         HIP_TRY(c, hipEventSynchronize(c->ev_done));
         c->in_flight.store(false);

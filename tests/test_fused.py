@@ -151,6 +151,46 @@ def test_two_rank_fused_cloud_on_one_gpu(crop, path, monkeypatch):
         cm.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("crop", [True, False])
+def test_rank_with_an_empty_share_still_merges_on_the_shared_grid(crop):
+    """Rank 0's only sensor delivered an empty cloud: its partial table is empty, but cm_merge_tables on it must
+    report and decode cells on the grid all ranks share (the crop box, or the all-reduced bounds)."""
+    from cloud_merger_amd import capi
+    from cloud_merger_amd.types import xyzi_cloud
+    rng = np.random.default_rng(3)
+    full = xyzi_cloud(rng.uniform(-4, 4, (30_000, 3)).astype(np.float32), rng.uniform(0, 9, 30_000).astype(np.float32))
+    empty = xyzi_cloud(np.zeros((0, 3), np.float32), np.zeros(0, np.float32))
+    sensors = [empty, full]
+    from cloud_merger_amd.types import MergeParams
+    params = MergeParams(leaf=(0.1, 0.15, 0.1), min_points_per_voxel=2)
+    if crop:
+        params.crop_min, params.crop_max = (-3.0, -3.5, -2.0), (3.5, 3.0, 2.5)
+    cms = [capi.CloudMerger(max_points_total=40_000, max_sensors=2, flags=capi.FLAG_OCCUPANCY) for _ in range(2)]
+    try:
+        for r, cm in enumerate(cms):
+            cm.set_transform(0, sensors[r].q_xyzw, sensors[r].t_xyz)
+            cm.submit(0, sensors[r])
+        bounds = None
+        if not crop:
+            lb = [b for b in (cm.local_bounds(params) for cm in cms) if b[2]]
+            assert len(lb) == 1
+            bounds = np.concatenate([lb[0][0], lb[0][1]])
+        r0 = cms[0].merge_partial(params, bounds)
+        r1 = cms[1].merge_partial(params, bounds)
+        assert r0.status == capi.EMPTY_INPUT and r1.status == capi.OK
+        assert list(r0.min_b) == list(r1.min_b) and list(r0.div_b) == list(r1.div_b)
+        ptr, n = cms[1].partial_device()
+        res = cms[0].merge_tables([ptr], [n], params)
+        cells, counts = cms[0].cells(res.n_out)
+        st, _, ref, rep = oracle.merge_voxelize(sensors, params, stable=True)
+        assert res.status == capi.OK and res.n_out == rep.n_out > 0
+        assert np.array_equal(cells, rep.cells) and np.array_equal(counts, rep.counts)
+    finally:
+        for cm in cms:
+            cm.close()
+
+
 _WORLD1_SCRIPT = r"""
 import sys
 import torch                                   # torch first: one HIP runtime per process (its bundled one)
