@@ -305,7 +305,7 @@ int build_frame(cm_ctx* c, const cm_params* p, bool consume, std::vector<std::un
         if (!sl.has_data) continue;          // stale optional sensors ride along like :141
         CmSensorDev& d = f.s[k++];
         d.data = static_cast<const unsigned char*>(sl.dptr);
-        d.n = sl.n; d.base = base; d.point_step = sl.step;
+        d.n = sl.n; d.base = base; d.point_step = sl.step; d.slot = s;
         d.off_x = sl.ox; d.off_y = sl.oy; d.off_z = sl.oz; d.off_i = sl.oi;
         const bool al16 = (reinterpret_cast<uintptr_t>(sl.dptr) & 15u) == 0;
         if (al16 && sl.step == 16 && sl.ox == 0 && sl.oy == 4 && sl.oz == 8 && sl.oi == 12) d.layout = CM_LAYOUT_XYZI16;
@@ -1378,6 +1378,7 @@ int cm_merge_tables(cm_ctx* c, const void* const* dev_tables, const uint64_t* n_
         d.data = static_cast<const unsigned char*>(dev_tables[t]);
         d.n = static_cast<uint32_t>(n_entries[t]);
         d.base = base;
+        d.slot = t;
         d.point_step = 32;
         const uint64_t nb = static_cast<uint64_t>(base) + round_up(d.n, CM_TILE);
         if (nb > c->cap_padded) return fail(c, CM_CAPACITY, "tables exceed cm_limits.max_points_total");

@@ -46,6 +46,9 @@ struct CmSensorDev {
     uint32_t off_x, off_y, off_z, off_i;   // off_i == 0xFFFFFFFF: no intensity
     uint32_t layout;
     float m[12];              // row-major 3x4 [R|t]
+    uint32_t slot;            // the caller's sensor number (slots without a cloud are skipped in s[]): what per-sensor
+                              // settings — the ground stage's slab tables — are indexed by
+    uint32_t _pad;
 };
 
 struct CmFrameDev {

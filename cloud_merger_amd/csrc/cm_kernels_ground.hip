@@ -54,8 +54,8 @@ __global__ __launch_bounds__(CM_BLOCK) void kg_classify(const CmFrameDev* __rest
         st->key_bits = 8;
         st->n_passes = 1;
     }
-    const uint32_t s = sensor_of_tile(fd, tile);
-    const CmSensorDev& sd = fd->s[s];
+    const CmSensorDev& sd = fd->s[sensor_of_tile(fd, tile)];
+    const uint32_t s = sd.slot;                          // slab tables, zone keys and planes go by the caller's sensor number
     float m[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) m[k] = sd.m[k];

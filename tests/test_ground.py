@@ -153,6 +153,39 @@ def test_empty_frame_after_a_ground_frame_reports_no_planes():
         assert not any(p.found or p.band_points or p.inliers for p in g["planes"])
 
 
+def test_slab_tables_follow_the_sensor_number_when_a_slot_is_empty():
+    """Sensor 0 has not delivered anything (the live node's optional top-middle Velodyne at start-up): sensors 1 and
+    2 must still be cut by THEIR slab tables, and their planes reported under their own numbers."""
+    rng = np.random.default_rng(35)
+    clouds = {1: xyzi_cloud(scene(rng, 40_000), rng.uniform(0, 255, 40_000)),
+              2: xyzi_cloud(scene(rng, 30_000, tilt=-0.02), rng.uniform(0, 255, 30_000))}
+    zones = [[(20.0, 40.0, 1.0)], FRONT, [(34.0, 26.0, 1.5), (4.0, 30.0, 0.5)]]
+    params = MergeParams(leaf=(0.1,) * 3, min_points_per_voxel=0, **ROI)
+    want_ng, want_g, want_planes = [], [], {}
+    for slot, c in clouds.items():
+        pts = oracle.make_points(np.stack([c.data["x"], c.data["y"], c.data["z"]], 1), c.data["intensity"])
+        cp = oracle.crop(oracle.transform(pts, oracle.quat_to_matrix(c.q_xyzw, c.t_xyz)), params.crop_min, params.crop_max)
+        keep, gr, pl = oracle.ground_split(cp, zones[slot], slot, GP)
+        want_ng.append(cp[keep]); want_g.append(cp[gr]); want_planes[slot] = pl
+    with capi.CloudMerger(max_points_total=70_000, max_sensors=3, flags=capi.FLAG_OCCUPANCY) as cm:
+        cm.set_ground_removal(capi.make_ground_params(zones, GP["max_iterations"], GP["threshold"], GP["probability"],
+                                                      GP["optimize"], GP["z_keep_max"], GP["seed"]))
+        for slot, c in clouds.items():
+            cm.set_transform(slot, c.q_xyzw, c.t_xyz)
+            cm.submit(slot, c)
+        res = cm.merge_voxelize(params)
+        assert res.status == capi.OK and res.n_sensors == 2
+        assert same_bits(a4(cm.merged(70_000)), xyzi_of(np.concatenate(want_ng)))
+        assert same_bits(a4(cm.ground(70_000)), xyzi_of(np.concatenate(want_g)))
+        planes = cm.ground_planes()
+    assert not any(planes[k].band_points for k in range(8))          # sensor 0: nothing
+    for slot, pls in want_planes.items():
+        for k, pl in enumerate(pls):
+            got = planes[slot * 8 + k]
+            assert pl is not None and got.found == pl.found and got.inliers == pl.n_inliers
+            assert np.abs(np.array(got.plane) - np.array(pl.plane)).max() <= 1e-6
+
+
 def test_band_outlier_filter_per_slab():
     """removeGround's outlierRemoval(:119): of a slab's band points that are not ground, those without a neighbour
     within 0.15 m (in the same slab's set) go. Sparse clutter in the band makes many of them lonely; two points
