@@ -74,12 +74,24 @@ def assert_centroids_close_or_exact(got, want, counts, cells, merged, leaf, sequ
         assert_centroids_close(got, want)
         return 0.0, 0.0
     assert_centroids_close(got[~is_big], want[~is_big])
-    pc = oracle.voxel_cells(merged, leaf)
-    m64 = xyzi_of(merged).astype(np.float64)
-    d_got = d_want = 0.0
-    for v in np.nonzero(is_big)[0]:
-        exact = m64[np.all(pc == cells[v], axis=1)].mean(axis=0)
-        d_got = max(d_got, float(np.abs(got[v].astype(np.float64) - exact)[:3].max()))
-        d_want = max(d_want, float(np.abs(want[v].astype(np.float64) - exact)[:3].max()))
+    pc = oracle.voxel_cells(merged, leaf).astype(np.int64)
+    bc = np.asarray(cells)[is_big].astype(np.int64)
+    lo = np.minimum(pc.min(axis=0), bc.min(axis=0))
+    ext = np.maximum(pc.max(axis=0), bc.max(axis=0)) - lo + 1
+
+    def lin(c):
+        c = c - lo
+        return (c[:, 2] * ext[1] + c[:, 1]) * ext[0] + c[:, 0]
+    big_keys = lin(bc)                                        # ascending: the voxels come in linear-index order
+    pk = lin(pc)
+    pos = np.searchsorted(big_keys, pk)
+    pos[pos == len(big_keys)] = 0
+    member = big_keys[pos] == pk
+    m64 = xyzi_of(merged).astype(np.float64)[member][:, :3]
+    idx = pos[member]
+    n_in = np.bincount(idx, minlength=len(big_keys)).astype(np.float64)
+    exact = np.stack([np.bincount(idx, weights=m64[:, a], minlength=len(big_keys)) for a in range(3)], axis=1) / n_in[:, None]
+    d_got = float(np.abs(got[is_big][:, :3].astype(np.float64) - exact).max())
+    d_want = float(np.abs(want[is_big][:, :3].astype(np.float64) - exact).max())
     assert d_got <= 1e-4, f"centroid of a voxel of more than {big} points is {d_got} m off the exact mean (oracle: {d_want})"
     return d_got, d_want
