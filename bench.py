@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+METRIC = "merged+voxelized points/sec at 5 cm leaf, 4\u00d71 M-pt inputs; HBM GB/s fraction"   # BASELINE.json's metric, verbatim
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md)
 HBM_COPY_GBS = 6290.0          # measured float4-copy ceiling, same guide (SURVEY.md §8d asks for both)
 
@@ -151,7 +152,7 @@ def main():
         elapsed = float(tmax.item())
 
     out = {
-        "metric": "merged+voxelized points/sec at 5 cm leaf, 4x1 M-pt inputs; HBM GB/s fraction",
+        "metric": METRIC,
         "value": world * args.steps * n_in / elapsed,
         "unit": "points/s",
         "n_gpus": world,
