@@ -135,6 +135,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Set-up, not measurement: the library allocates its work buffers on a context's first frame and, without a
+    # crop box, takes its first box from one min/max pass — run one frame per context so that --warmup 0 still
+    # times steady-state frames only.
+    for c in cms:
+        enqueue(c)
+        if c.wait().status != capi.OK:
+            raise SystemExit("set-up frame failed")
     if args.warmup:
         run_steps(args.warmup)
     barrier()
