@@ -867,6 +867,10 @@ int wait_frame(cm_ctx* c, cm_result* res) {
             }
             return fail(c, CM_INTERNAL, "device reported an internal error");
         }
+        if (h.status == CM_DEV_ABORTED) {                  // (a stage gave up and nobody redid the frame: cannot happen)
+            c->pending = false;
+            return fail(c, CM_INTERNAL, "a device stage aborted the frame");
+        }
         if (h.status == CM_DEV_OUTLIER_GRID) {
             c->pending = false;
             return fail(c, CM_CAPACITY, "outlier radius too small for the cloud's extent (radius grid exceeds its limits)");

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_keys(const CmFrameDev* __restrict_
     if (use_cell && g.status == CM_DEV_OK &&
         static_cast<unsigned long long>(g.div_b[1]) * static_cast<unsigned long long>(g.div_b[2]) > CM_ROW_TABLE_CAP)
         g.status = CM_DEV_OUTLIER_GRID;
-    if (st_outlier && st_outlier->status == CM_DEV_OUTLIER_GRID) g.status = CM_DEV_OUTLIER_GRID;
+    if (st_outlier && (st_outlier->status == CM_DEV_OUTLIER_GRID || st_outlier->status == CM_DEV_ABORTED)) g.status = st_outlier->status;
     if (tile == 0 && threadIdx.x == 0) {
         st->status = g.status;
         st->n_valid_k0 = g.n_valid_k0;

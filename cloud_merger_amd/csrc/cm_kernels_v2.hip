@@ -141,7 +141,8 @@ __global__ __launch_bounds__(CM2_BLOCK) void k2_hist0(const CmFrameDev* __restri
     for (uint32_t k = tile * CM2_BLOCK + threadIdx.x; k < n_tile_state; k += gridDim.x * CM2_BLOCK) tile_state[k] = 0ull;
 
     if (tile == 0 && threadIdx.x == 0) {                 // the box and its grid, as the host set them up
-        st->status = (st_outlier && st_outlier->status == CM_DEV_OUTLIER_GRID) ? CM_DEV_OUTLIER_GRID : CM_DEV_OK;
+        const int32_t so = st_outlier ? st_outlier->status : CM_DEV_OK;      // a stage before this one failed: so does the frame
+        st->status = (so == CM_DEV_OUTLIER_GRID || so == CM_DEV_ABORTED) ? so : CM_DEV_OK;
         for (int a = 0; a < 3; ++a) {
             st->min_p[a] = grid_mode == 2 ? fd->ext_min[a] : fd->crop_min[a];
             st->max_p[a] = grid_mode == 2 ? fd->ext_max[a] : fd->crop_max[a];
@@ -605,7 +606,12 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
         }
     }
     const uint32_t m = (a == 0xFFFFFFFFu || too_big) ? 0u : nom + ext - a;
-    if (too_big && threadIdx.x == 0) host_state[offsetof(CmFrameState, err) / 4] = WRITEBACK ? CM_DEV_ERR_BUCKET_PRE : CM_DEV_ERR_BUCKET;
+    if (too_big && threadIdx.x == 0) {
+        host_state[offsetof(CmFrameState, err) / 4] = WRITEBACK ? CM_DEV_ERR_BUCKET_PRE : CM_DEV_ERR_BUCKET;
+        // This tile's part of the sorted arrays stays unwritten: the row table and the neighbour search behind this
+        // kernel would index memory with whatever the buffers held before. They all leave on a status other than OK.
+        if (WRITEBACK) st->status = CM_DEV_ABORTED;
+    }
 
     PH(2);
     // ---- sort the owned slots [a, a+m) by key: LSD over the bits in which the keys of this tile can

@@ -445,6 +445,13 @@ def test_outlier_stage_hands_back_an_overfull_radius_cell():
                     crop_min=(-25, -25, -25), crop_max=(25, 25, 25))
     st, merged_ref, ref, rep = oracle.merge_voxelize(s, p, stable=True)
     with capi.CloudMerger(max_points_total=len(xyz), max_sensors=1, flags=capi.FLAG_OCCUPANCY) as cm:
+        # First a frame that leaves invalid keys (0xFFFFFFFF) and large indices behind in the sort buffers: the tile that
+        # gives up leaves its part of them as it was, and nothing after it may index memory with that (the row table
+        # once did: a memory fault in a long differential run).
+        junk = xyz.copy()
+        junk[::3] = np.nan
+        cm.submit_all([xyzi_cloud(junk, np.zeros(len(junk), np.float32), is_dense=False)])
+        assert cm.merge_voxelize(MergeParams(leaf=(0.05,) * 3, outlier_radius=0.3, outlier_min_neighbors=2)).status == capi.OK
         flags = []
         for _ in range(3):
             cm.submit_all(s)
