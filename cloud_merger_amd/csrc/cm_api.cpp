@@ -250,8 +250,8 @@ int set_slot_cloud(cm_ctx* c, uint32_t sensor, const void* data, bool on_device,
     if (!c) return CM_BAD_ARG;
     if (sensor >= c->max_sensors) return fail(c, CM_BAD_ARG, "sensor index out of range");
     if (n && !data) return fail(c, CM_BAD_ARG, "null payload");
-    const uint32_t need = (oi == CM_NO_FIELD) ? 0 : oi + 4;
-    if (n && (step < 12 || ox + 4 > step || oy + 4 > step || oz + 4 > step || need > step))
+    auto fits = [step](uint32_t off) { return static_cast<uint64_t>(off) + 4u <= step; };   // (no 32-bit wrap-around)
+    if (n && (step < 12 || !fits(ox) || !fits(oy) || !fits(oz) || (oi != CM_NO_FIELD && !fits(oi))))
         return fail(c, CM_BAD_ARG, "field offsets do not fit point_step");
     if (n > c->max_points) return fail(c, CM_CAPACITY, "cloud larger than cm_limits.max_points_total");
     HIP_TRY(c, hipSetDevice(c->device));

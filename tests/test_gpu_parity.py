@@ -504,6 +504,27 @@ def test_rejected_arguments_do_not_consume_the_frame():
         assert cm.merge_voxelize(params).status == capi.NOT_READY   # ... and the accepted call consumed them
 
 
+def test_submit_rejects_layouts_that_do_not_fit_the_point_step():
+    """Offsets are caller data: anything that would read outside a point (also through 32-bit wrap-around of
+    offset + 4) is refused on the host and leaves the slot as it was."""
+    import ctypes as C
+    buf = np.zeros((100, 4), np.float32)
+    with capi.CloudMerger(max_points_total=1000, max_sensors=2) as cm:
+        L = cm._lib
+        def submit(step, ox, oy, oz, oi, n=100, sensor=0):
+            return L.cm_submit_cloud(cm._ctx, sensor, buf.ctypes.data, n, step, ox, oy, oz, oi)
+        assert submit(16, 0, 4, 8, 12) == capi.OK
+        cm.clear(0)
+        for args in [(8, 0, 4, 8, 12), (16, 0, 4, 13, 12), (16, 14, 4, 8, 12), (16, 0, 4, 8, 13),
+                     (16, 0, 4, 8, 0xFFFFFFFE), (16, 0xFFFFFFFD, 4, 8, 12), (16, 0, 0xFFFFFFFC, 8, 12)]:
+            assert submit(*args) == capi.BAD_ARG, args
+        assert submit(16, 0, 4, 8, capi.NO_FIELD) == capi.OK       # "no intensity field" is not an offset
+        cm.clear(0)
+        assert submit(16, 0, 4, 8, 12, sensor=2) == capi.BAD_ARG
+        assert submit(16, 0, 4, 8, 12, n=1001) == capi.CAPACITY
+        assert cm.merge_voxelize(MergeParams(leaf=(0.1,) * 3)).status == capi.NOT_READY   # nothing got in
+
+
 def test_concurrent_ingest_threads_and_consumer():
     """The calling pattern of the reference node: one ingest thread per sensor (AsyncSpinner(6), :513)
     calling cm_submit_cloud while the main loop calls cm_merge_voxelize (:574-577). Every fused frame
