@@ -114,6 +114,7 @@ struct cm_ctx {
     void *rec_a = nullptr, *rec_b = nullptr;      // 16-byte point records, ping-pong
     unsigned char* dig = nullptr;        // next digit of every record
     unsigned long long* tile_state = nullptr;     // published kept-voxel counts of the local finish
+    uint32_t* wave_cnt = nullptr;                 // records k2_hist0 packed per wave (frames whose crop box drops most points)
     float* records = nullptr;            // min/max/count per tile
     bool pred_ok = false;                // a box predicted from an earlier frame's bounds
     float pred_min[3] = {0, 0, 0}, pred_max[3] = {0, 0, 0};
@@ -124,6 +125,7 @@ struct cm_ctx {
     uint32_t pre_bucket_off = 0;         // frames for which the outlier stage sorts with the general kernels (a bucket overflowed)
     uint32_t pre_bucket_backoff = 16;
     bool pre_bucket = false;             // this frame's outlier stage may sort with the bucket kernels
+    bool last_packed = false;            // the voxel stage's k2_hist0 packed the survivors (CM_PATH_PACKED)
     bool last_v2 = false, last_predicted = false;
     bool post_bucket = false;            // the frame's pre-stages (ground / outlier removal) run first, then the bucket path
     uint32_t post_g = 0, post_low = 0;
@@ -232,7 +234,7 @@ void free_all(cm_ctx* c) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(c->keys_a); F(c->keys_b); F(c->vals_a); F(c->vals_b); F(c->hist); F(c->totals);
     F(c->seg_counts); F(c->seg_tile_counts); F(c->seg_groups); F(c->grp); F(c->partials); F(c->out_key); F(c->out_cnt); F(c->merged_total); F(c->out); F(c->merged); F(c->partial); F(c->table_entries); F(c->mask); F(c->sorted_pts); F(c->rows); F(c->d_state_o);
-    F(c->rec_a); F(c->rec_b); F(c->dig); F(c->tile_state); F(c->records);
+    F(c->rec_a); F(c->rec_b); F(c->dig); F(c->tile_state); F(c->wave_cnt); F(c->records);
     F(c->d_ground); F(c->d_state_g); F(c->gmask); F(c->zone_off); F(c->d_planes); F(c->hyp0); F(c->valid0); F(c->counts0); F(c->chunk_sums); F(c->bmask); F(c->zcode);
     F(c->d_frame); F(c->d_state[0]); F(c->d_state[1]);
     if (c->h_state) (void)hipHostFree(c->h_state);
@@ -406,6 +408,7 @@ int bucket_buffers(cm_ctx* c) {
     if (!c->dig) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->dig), npad));
     if (!c->tile_state) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->tile_state), (npad / 1024 + 2) * 8));
     if (!c->records) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->records), static_cast<size_t>(c->cap_tiles) * 32));
+    if (!c->wave_cnt) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->wave_cnt), static_cast<size_t>(c->cap_tiles) * CM2_WAVES * 4));
     return CM_OK;
 }
 
@@ -418,6 +421,13 @@ uint32_t bucket_passes(uint32_t kb, uint64_t est, uint32_t extra) {
     g += extra;
     if (g > 1 && 8 * (g - 1) >= kb) return 0;         // nothing left for the local finish to add
     return g <= CM_MAX_PASSES ? g : 0;
+}
+
+// A crop box that dropped more than half of the last frame's points: k2_hist0 then also packs the survivors' records
+// (into the record buffer the first scatter does not write), and the first scatter reads those instead of going
+// through every raw point a second time — the raw clouds are read once, not twice.
+bool pack_survivors(const cm_ctx* c) {
+    return c->frame.crop_enable && c->last_n_merged && 2 * c->last_n_merged < c->n_in;
 }
 
 int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits, const unsigned char* mask,
@@ -447,10 +457,12 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
     uint32_t* grp0_next = c->grp + gstride * ((c->frame_seq & 1u) ^ 1u);
     ++c->frame_seq;
     c->frame_mask = mask;
+    const bool pack = !predicted && pack_survivors(c);
+    c->last_packed = pack;
     prof_mark(c, "k2_hist0");
     cmk2_hist0(st, c->d_frame, state, c->hist, grp0, grp0_next, c->grp + 2 * gstride, gw, static_cast<uint32_t>(gstride),
                c->tile_state, f.n_padded / 1024 + 2, c->records, grid_mode, predicted ? 1 : 0, low_bits, n_global, nt, mask,
-               st_outlier);
+               st_outlier, 0, pack ? c->rec_b : nullptr, c->wave_cnt);
     for (uint32_t pass = 0; pass < n_global; ++pass) {
         uint32_t* grp = pass == 0 ? grp0 : c->grp + 2 * gstride + static_cast<size_t>(pass - 1) * gw;
         if (pass > 0) { prof_mark(c, "k2_hist"); cmk2_hist(st, state, c->dig, c->hist, grp, nt); }
@@ -460,7 +472,7 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
         void* out = (pass & 1u) ? c->rec_b : c->rec_a;
         cmk2_scatter(st, pass == 0, c->d_frame, state, in, out, c->dig, c->hist, grp, big ? c->totals : nullptr,
                      low_bits + 8 * pass, pass + 1 < n_global ? low_bits + 8 * (pass + 1) : 32u, nt, n_groups,
-                     f.n_padded, c->records, nt, predicted ? 1 : 0, mask);
+                     f.n_padded, c->records, nt, predicted ? 1 : 0, mask, 0, (pack && pass == 0) ? c->rec_b : nullptr, c->wave_cnt);
     }
     prof_mark(c, "k2_local");
     cmk2_local(st, c->d_frame, state, state_next, c->h_state_dev, ((n_global - 1) & 1u) ? c->rec_b : c->rec_a,
@@ -675,9 +687,11 @@ int launch_classic(cm_ctx* c, const cm_params* p, int mode, int grid_mode, uint3
             uint32_t* grp0 = c->grp + gstride * (c->frame_seq & 1u);
             uint32_t* grp0_next = c->grp + gstride * ((c->frame_seq & 1u) ^ 1u);
             ++c->frame_seq;
+            const bool pack = pack_survivors(c);
             prof_mark(c, "k2_hist0(outlier)");
             cmk2_hist0(st, c->d_frame, c->d_state_o, c->hist, grp0, grp0_next, c->grp + 2 * gstride, gw, static_cast<uint32_t>(gstride),
-                       c->tile_state, f.n_padded / 1024 + 2, c->records, 1, 0, low, g, nt, in, nullptr, 1);
+                       c->tile_state, f.n_padded / 1024 + 2, c->records, 1, 0, low, g, nt, in, nullptr, 1,
+                       pack ? c->rec_b : nullptr, c->wave_cnt);
             for (uint32_t pass = 0; pass < g; ++pass) {
                 uint32_t* grp = pass == 0 ? grp0 : c->grp + 2 * gstride + static_cast<size_t>(pass - 1) * gw;
                 if (pass > 0) { prof_mark(c, "k2_hist"); cmk2_hist(st, c->d_state_o, c->dig, c->hist, grp, nt); }
@@ -685,7 +699,7 @@ int launch_classic(cm_ctx* c, const cm_params* p, int mode, int grid_mode, uint3
                 prof_mark(c, "k2_scatter(outlier)");
                 cmk2_scatter(st, pass == 0, c->d_frame, c->d_state_o, (pass & 1u) ? c->rec_a : c->rec_b, (pass & 1u) ? c->rec_b : c->rec_a,
                              c->dig, c->hist, grp, big ? c->totals : nullptr, low + 8 * pass, pass + 1 < g ? low + 8 * (pass + 1) : 32u,
-                             nt, n_groups, f.n_padded, c->records, nt, 0, in, 1);
+                             nt, n_groups, f.n_padded, c->records, nt, 0, in, 1, (pack && pass == 0) ? c->rec_b : nullptr, c->wave_cnt);
             }
             prof_mark(c, "k2_local(sort)");
             cmk2_local_sort(st, c->d_frame, c->d_state_o, c->h_state_dev, ((g - 1) & 1u) ? c->rec_b : c->rec_a,
@@ -884,7 +898,8 @@ int wait_frame(cm_ctx* c, cm_result* res) {
         }
         r.key_bits = h.key_bits;
         r.sort_passes = h.n_passes;
-        r.path_flags = (c->lds_rank ? 1u : 0u) | (c->last_v2 ? 2u : 0u) | (c->last_predicted ? 4u : 0u) | (redone ? 8u : 0u);
+        r.path_flags = (c->lds_rank ? 1u : 0u) | (c->last_v2 ? 2u : 0u) | (c->last_predicted ? 4u : 0u) | (redone ? 8u : 0u) |
+                       ((c->last_v2 && c->last_packed) ? 16u : 0u);
         if (c->last_predicted && h.status == CM_OK) {
             // The device sorted by cells of the predicted box (same order); the grid PCL itself would
             // report comes from the cloud's exact bounds, which the frame also produced (A.4 steps 2, 4).

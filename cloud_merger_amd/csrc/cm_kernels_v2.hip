@@ -118,7 +118,8 @@ __device__ __forceinline__ uint32_t sensor_of_slot(const CmFrameDev* __restrict_
 // digit among the valid points; grid set-up recorded by workgroup 0; min/max/count record per tile.
 // Also clears what the later kernels of this frame (and the first kernel of the next) accumulate into.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(CM2_BLOCK) void k2_hist0(const CmFrameDev* __restrict__ fd,
+template <bool PACK>
+__global__ __launch_bounds__(CM2_BLOCK, PACK ? 8 : 1) void k2_hist0(const CmFrameDev* __restrict__ fd,
                                                       CmFrameState* __restrict__ st,
                                                       uint32_t* __restrict__ hist,
                                                       uint32_t* __restrict__ grp_acc,
@@ -130,7 +131,11 @@ __global__ __launch_bounds__(CM2_BLOCK) void k2_hist0(const CmFrameDev* __restri
                                                       float* __restrict__ records,
                                                       int grid_mode, int check_box, uint32_t shift0, uint32_t n_global_passes,
                                                       const unsigned char* __restrict__ mask,
-                                                      const CmFrameState* __restrict__ st_outlier, int use_cell) {
+                                                      const CmFrameState* __restrict__ st_outlier, int use_cell,
+                                                      float4* __restrict__ compact_out, uint32_t* __restrict__ wave_cnt) {
+    // compact_out (frames whose crop box drops most points): the surviving records are written here as well, wave w of
+    // tile t packing its own in slot order at [t * 4096 + w * 512, ...) and leaving their number in wave_cnt[t * 8 + w];
+    // the first scatter then reads these few records instead of every raw point a second time.
     __shared__ uint32_t lh[CM_RADIX];
     __shared__ float s_mm[CM2_WAVES][6];
     __shared__ uint32_t s_cnt[CM2_WAVES];
@@ -172,11 +177,14 @@ __global__ __launch_bounds__(CM2_BLOCK) void k2_hist0(const CmFrameDev* __restri
     float mn0 = inf, mn1 = inf, mn2 = inf, mx0 = -inf, mx1 = -inf, mx2 = -inf;
     uint32_t cnt = 0;
     bool any_out = false;
+    const bool all_fields = fd->downsample_all != 0;
+    uint32_t wrun = 0;                                    // records this wave has packed so far (wave-uniform)
 #pragma unroll
     for (int r = 0; r < CM2_ITEMS; ++r) {
         const float x = xf_row(m[0], m[1], m[2], m[3], p[r].x, p[r].y, p[r].z);
         const float y = xf_row(m[4], m[5], m[6], m[7], p[r].x, p[r].y, p[r].z);
         const float z = xf_row(m[8], m[9], m[10], m[11], p[r].x, p[r].y, p[r].z);
+        bool keep = false;
         if (point_valid(x, y, z, crop, fd->crop_min, fd->crop_max) && (!mask || mask[slot0 + r * 64])) {
             bool in;
             const uint32_t key = key_of(b, x, y, z, &in);
@@ -190,8 +198,19 @@ __global__ __launch_bounds__(CM2_BLOCK) void k2_hist0(const CmFrameDev* __restri
                 in = true;
             }
             if (in) atomicAdd(&lh[(key >> shift0) & (CM_RADIX - 1)], 1u);
+            keep = in;
+        }
+        if (PACK) {
+            const unsigned long long bal = __ballot(keep);
+            if (keep) {
+                const uint32_t at = wrun + static_cast<uint32_t>(__popcll(bal & ((1ull << lane) - 1ull)));
+                compact_out[static_cast<size_t>(tile) * CM_TILE + w * (64 * CM2_ITEMS) + at] =
+                    make_float4(x, y, z, use_cell ? __uint_as_float(slot0 + r * 64) : (all_fields ? p[r].i : 0.f));
+            }
+            wrun += static_cast<uint32_t>(__popcll(bal));
         }
     }
+    if (PACK && lane == 0) wave_cnt[tile * CM2_WAVES + w] = wrun;
     if (predicted) {
         if (any_out) s_out = 1u;
         mn0 = wave_min_f32_l63(mn0); mn1 = wave_min_f32_l63(mn1); mn2 = wave_min_f32_l63(mn2);
@@ -272,7 +291,9 @@ __global__ __launch_bounds__(CM2_BLOCK, 3) void k2_scatter(const CmFrameDev* __r
                                                            uint32_t n_groups, uint32_t n_padded,
                                                            const float* __restrict__ records,
                                                            uint32_t n_records, int fold,
-                                                           const unsigned char* __restrict__ mask, int use_cell) {
+                                                           const unsigned char* __restrict__ mask, int use_cell,
+                                                           const float4* __restrict__ compact_in,
+                                                           const uint32_t* __restrict__ wave_cnt) {
     __shared__ float4 srec[CM_TILE / 2];                // staging in two halves: 41 KB per workgroup, three per CU
     __shared__ uint32_t whist[CM2_WAVES][CM_RADIX];
     __shared__ uint32_t gofs[CM_RADIX];
@@ -291,7 +312,23 @@ __global__ __launch_bounds__(CM2_BLOCK, 3) void k2_scatter(const CmFrameDev* __r
     float4 rec[CM2_ITEMS];
     uint32_t key[CM2_ITEMS];
     uint32_t vmask = 0;
-    if (FIRST) {
+    if (FIRST && compact_in) {
+        // k2_hist0 left this tile's surviving records packed per wave, in slot order: same (wave, round, lane) layout
+        // as the raw read below, so the ranking stays stable; nothing to transform or to test again.
+        uint32_t tile_cnt = 0;
+#pragma unroll
+        for (int q = 0; q < CM2_WAVES; ++q) tile_cnt += wave_cnt[tile * CM2_WAVES + q];
+        if (tile_cnt == 0 && tile != 0) return;            // nothing of this tile survived (tile 0 also records the frame's totals)
+        const uint32_t cw = wave_cnt[tile * CM2_WAVES + w];
+        const float4* __restrict__ src = compact_in + static_cast<size_t>(tile) * CM_TILE + w * (64 * CM2_ITEMS);
+#pragma unroll
+        for (int r = 0; r < CM2_ITEMS; ++r) {
+            const uint32_t i = r * 64 + lane;
+            rec[r] = src[i < cw ? i : 0u];                 // (unconditional load; slot 0 of the wave's range is always mapped)
+            key[r] = key_of(b, rec[r]);
+            if (i < cw) vmask |= 1u << r;
+        }
+    } else if (FIRST) {
         const CmSensorDev& sd = fd->s[sensor_of_slot(fd, tile * CM_TILE)];
         float m[12];
 #pragma unroll
@@ -862,10 +899,15 @@ void cmk2_hist0(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t*
                 uint32_t* grp_clear_a, uint32_t* grp_clear_b, uint32_t n_group_words, uint32_t n_clear_a_words,
                 unsigned long long* tile_state, uint32_t n_tile_state, float* records, int grid_mode, int check_box,
                 uint32_t shift0, uint32_t n_global_passes, uint32_t n_tiles, const unsigned char* mask,
-                const CmFrameState* st_outlier, int use_cell) {
-    hipLaunchKernelGGL(k2_hist0, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, st, hist, grp_acc, grp_clear_a, grp_clear_b,
-                       n_group_words, n_clear_a_words, tile_state, n_tile_state, records, grid_mode, check_box, shift0,
-                       n_global_passes, mask, st_outlier, use_cell);
+                const CmFrameState* st_outlier, int use_cell, void* compact_out, uint32_t* wave_cnt) {
+    if (compact_out)
+        hipLaunchKernelGGL(k2_hist0<true>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, st, hist, grp_acc, grp_clear_a, grp_clear_b,
+                           n_group_words, n_clear_a_words, tile_state, n_tile_state, records, grid_mode, check_box, shift0,
+                           n_global_passes, mask, st_outlier, use_cell, reinterpret_cast<float4*>(compact_out), wave_cnt);
+    else
+        hipLaunchKernelGGL(k2_hist0<false>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, st, hist, grp_acc, grp_clear_a, grp_clear_b,
+                           n_group_words, n_clear_a_words, tile_state, n_tile_state, records, grid_mode, check_box, shift0,
+                           n_global_passes, mask, st_outlier, use_cell, nullptr, nullptr);
 }
 void cmk2_hist(hipStream_t s, const CmFrameState* st, const unsigned char* dig, uint32_t* hist, uint32_t* grp,
                uint32_t n_tiles) {
@@ -874,15 +916,18 @@ void cmk2_hist(hipStream_t s, const CmFrameState* st, const unsigned char* dig, 
 void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, CmFrameState* st, const void* rec_in, void* rec_out,
                   unsigned char* dig_out, const uint32_t* hist, const uint32_t* grp, const uint32_t* totals,
                   uint32_t shift, uint32_t next_shift, uint32_t n_tiles, uint32_t n_groups, uint32_t n_padded,
-                  const float* records, uint32_t n_records, int fold, const unsigned char* mask, int use_cell) {
+                  const float* records, uint32_t n_records, int fold, const unsigned char* mask, int use_cell,
+                  const void* compact_in, const uint32_t* wave_cnt) {
     const float4* in = reinterpret_cast<const float4*>(rec_in);
     float4* o = reinterpret_cast<float4*>(rec_out);
     if (first)
         hipLaunchKernelGGL(k2_scatter<true>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, st, in, o, dig_out, hist, grp,
-                           totals, shift, next_shift, n_groups, n_padded, records, n_records, fold, mask, use_cell);
+                           totals, shift, next_shift, n_groups, n_padded, records, n_records, fold, mask, use_cell,
+                           reinterpret_cast<const float4*>(compact_in), wave_cnt);
     else
         hipLaunchKernelGGL(k2_scatter<false>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, st, in, o, dig_out, hist, grp,
-                           totals, shift, next_shift, n_groups, n_padded, records, n_records, fold, mask, use_cell);
+                           totals, shift, next_shift, n_groups, n_padded, records, n_records, fold, mask, use_cell,
+                           reinterpret_cast<const float4*>(compact_in), wave_cnt);
 }
 void cmk2_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next, uint32_t* host_state,
                 const void* rec, unsigned long long* tile_state, uint32_t* ticket, void* out, uint32_t* out_key,

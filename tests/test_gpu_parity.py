@@ -24,7 +24,7 @@ def sort_path(request, monkeypatch):
     return request.param
 
 
-BUCKET, PREDICTED, REDONE = 2, 4, 8          # cm_result.path_flags (CM_PATH_*)
+BUCKET, PREDICTED, REDONE, PACKED = 2, 4, 8, 16          # cm_result.path_flags (CM_PATH_*)
 
 STATUS = {"OK": capi.OK, "EMPTY_INPUT": capi.EMPTY_INPUT, "GRID_OVERFLOW": capi.GRID_OVERFLOW}
 
@@ -620,6 +620,34 @@ def test_randomized_differential(seed):
 
 
 # ---- bucket path: predicted box, hand-back to the general path ---------------------------------
+@pytest.mark.parametrize("outlier", [False, True])
+def test_crop_heavy_frames_pack_the_survivors(sort_path, outlier):
+    """The reference ROI keeps a few percent of cfg3's points: from the second frame on the bucket path packs the
+    survivors while it counts them (CM_PATH_PACKED) and the first scatter reads those records — same result, frame
+    after frame, also when the next frame keeps far more (the packing is then switched off again)."""
+    sensors, params = synth.config3(n_per_sensor=120_000, n_sensors=6, min_pts=0, leaf=0.05)
+    if outlier:
+        params.outlier_radius, params.outlier_min_neighbors = 0.3, 1
+    wide = MergeParams(leaf=params.leaf, min_points_per_voxel=0, crop_min=(-45.0, -45.0, -3.0), crop_max=(45.0, 45.0, 7.0))
+    with capi.CloudMerger(max_points_total=720_000, max_sensors=6, flags=capi.FLAG_OCCUPANCY) as cm:
+        flags = []
+        for p in (params, params, params, wide, wide, params):
+            st, merged, out, rep = oracle.merge_voxelize(sensors, p, threads=4, stable=True)
+            g = run_gpu(sensors, p, cm=cm)
+            assert g["res"].status == st == oracle.OK and g["res"].n_out == rep.n_out and g["res"].n_merged == rep.n_merged
+            assert same_bits(g["merged"], xyzi_of(merged))
+            assert np.array_equal(g["cells"], rep.cells) and np.array_equal(g["counts"], rep.counts)
+            assert_centroids_close(g["out"], xyzi_of(out))
+            if g["res"].path_flags & BUCKET:
+                assert same_bits(g["out"], xyzi_of(out))
+            flags.append(bool(g["res"].path_flags & PACKED))
+        assert rep.n_merged * 2 < sum(s.n for s in sensors)
+    if g["res"].path_flags & BUCKET:
+        assert flags == [False, True, True, True, False, False]     # decided from the frame before
+    else:
+        assert not any(flags)
+
+
 def test_predicted_box_miss_is_redone_and_learned(sort_path):
     """No crop box: the bucket path sorts in the previous frame's bounds plus a margin. A frame whose
     cloud leaves that box is found out on the device, redone by the general path (same answer), and
