@@ -232,30 +232,37 @@ __global__ __launch_bounds__(1024) void k_gscan(const CmFrameState* __restrict__
                                                 uint32_t* __restrict__ grp,
                                                 uint32_t* __restrict__ totals,
                                                 uint32_t pass, uint32_t n_groups) {
+    constexpr int GB = 32;            // groups fetched together: a frame of 16 M points (244 groups) costs two round trips per phase
     __shared__ uint32_t chunk_total[4][CM_RADIX];
     if (st->status != CM_DEV_OK || pass >= st->n_passes) return;
     const uint32_t d = threadIdx.x & (CM_RADIX - 1), c = threadIdx.x >> 8;
     const uint32_t per = (n_groups + 3) / 4;
     const uint32_t g0 = c * per, g1 = min(g0 + per, n_groups);
     uint32_t sum = 0;
-    for (uint32_t g = g0; g < g1; g += 8) {
-        uint32_t v[8];
+    for (uint32_t g = g0; g < g1; g += GB) {
+        uint32_t v[GB];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = (g + q < g1) ? grp[static_cast<size_t>(g + q) * CM_RADIX + d] : 0u;
+        for (int q = 0; q < GB; ++q) {                    // unconditional loads (clamped), all in flight together
+            const uint32_t x = grp[static_cast<size_t>(min(g + q, g1 - 1u)) * CM_RADIX + d];
+            v[q] = (g + q < g1) ? x : 0u;
+        }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) sum += v[q];
+        for (int q = 0; q < GB; ++q) sum += v[q];
     }
     chunk_total[c][d] = sum;
     __syncthreads();
     uint32_t run = 0;
     for (uint32_t q = 0; q < c; ++q) run += chunk_total[q][d];
     if (c == 3) totals[d] = run + sum;
-    for (uint32_t g = g0; g < g1; g += 8) {
-        uint32_t v[8];
+    for (uint32_t g = g0; g < g1; g += GB) {
+        uint32_t v[GB];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = (g + q < g1) ? grp[static_cast<size_t>(g + q) * CM_RADIX + d] : 0u;
+        for (int q = 0; q < GB; ++q) {                    // unconditional loads (clamped), all in flight together
+            const uint32_t x = grp[static_cast<size_t>(min(g + q, g1 - 1u)) * CM_RADIX + d];
+            v[q] = (g + q < g1) ? x : 0u;
+        }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < GB; ++q) {
             if (g + q < g1) grp[static_cast<size_t>(g + q) * CM_RADIX + d] = run;
             run += v[q];
         }
