@@ -347,6 +347,9 @@ __global__ __launch_bounds__(CM_BLOCK, 4) void k_scatter(CmFrameState* __restric
         const uint32_t per = gridDim.x / 8;
         if (blockIdx.x < per * 8) tile = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
     }
+    // After pass 0 only the valid items are left, and pass 0 recorded how many: a crop box may have dropped most
+    // of the frame, and the tiles past the end have nothing to read.
+    if (!FIRST && tile * CM_TILE >= st->n_valid) return;
     const uint32_t shift = pass * CM_RADIX_BITS;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t first = tile * CM_TILE + w * (64 * CM_ITEMS) + lane;

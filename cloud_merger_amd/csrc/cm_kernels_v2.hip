@@ -305,6 +305,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 3) void k2_scatter(const CmFrameDev* __r
         const uint32_t per = gridDim.x / 8;              // contiguous tile range per XCD (see k_scatter)
         if (blockIdx.x < per * 8) tile = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
     }
+    if (!FIRST && tile * CM_TILE >= st->n_valid) return;    // (the first pass recorded how many records are left: see k_scatter)
     const BoxGrid b = box_grid_of(fd, use_cell);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t first = tile * CM_TILE + w * (64 * CM2_ITEMS) + lane;
