@@ -82,3 +82,14 @@ def test_bad_arguments_are_status_codes(lib):
     assert lib.cm_create(C.byref(ctx), 0, C.byref(lim)) == capi.BAD_ARG
     assert lib.cm_destroy(None) == capi.BAD_ARG
     assert lib.cm_merge_voxelize(None, None, None) == capi.BAD_ARG
+
+
+def test_scripts_compile():
+    """The measurement and differential-run scripts under scripts/ are not imported by the suite (they need a GPU and
+    minutes of time): at least keep them syntactically alive."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "scripts", "*.py")))
+    assert len(files) >= 8
+    for f in files:
+        compile(open(f).read(), f, "exec")
