@@ -21,11 +21,15 @@ CAP = 400_000
 
 
 def cloud(rng):
-    kind = rng.choice(["scene", "scene", "scene", "flat", "line", "same", "tiny", "empty", "steep"])
+    kind = rng.choice(["scene", "scene", "scene", "wide", "wide", "flat", "line", "same", "tiny", "empty", "steep"])
     n = int(rng.choice([300, 3000, 20_000, 60_000]))
     if kind == "scene":
         xyz = scene(rng, n, tilt=float(rng.uniform(-0.03, 0.03)), ground_sigma=float(rng.choice([0.0, 0.01, 0.05])),
                     obj_frac=float(rng.choice([0.0, 0.25, 0.9])))
+    elif kind == "wide":                                   # a 360-degree scan: the ROI keeps a small part (survivor packing, CM_PATH_PACKED)
+        xyz = scene(rng, n, tilt=float(rng.uniform(-0.01, 0.01)))
+        xyz[:, 0] = rng.uniform(-120, 120, n).astype(np.float32)
+        xyz[:, 1] = rng.uniform(-60, 60, n).astype(np.float32)
     elif kind == "flat":                                   # exact plane z = 0: every sample fits every point
         xyz = np.stack([rng.uniform(-15, 60, n), rng.uniform(-5, 5, n), np.zeros(n)], 1).astype(np.float32)
     elif kind == "line":                                   # collinear points: no sample gives a plane
@@ -53,7 +57,7 @@ def slabs(rng):
 
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 log = open(os.path.join(ROOT, "gpurun_out", f"fuzz_ground_{os.environ.get('CM_PATH', 'auto')}_{seed0}.log"), "w")
-t_end, frame, n_planes, n_found = time.time() + budget, 0, 0, 0
+t_end, frame, n_planes, n_found, n_packed = time.time() + budget, 0, 0, 0, 0
 with capi.CloudMerger(max_points_total=CAP, max_sensors=6, flags=capi.FLAG_OCCUPANCY) as cm:
     while time.time() < t_end:
         n_s = int(rng.integers(1, 7))
@@ -90,7 +94,8 @@ with capi.CloudMerger(max_points_total=CAP, max_sensors=6, flags=capi.FLAG_OCCUP
             assert np.array_equal(g["cells"], rep.cells) and np.array_equal(g["counts"], rep.counts), ctx
             assert_centroids_close_or_exact(a4(g["out"]), xyzi_of(vox), rep.counts, rep.cells, want_ng, params.leaf,
                                             sequential=bool(g["res"].path_flags & 2))
+        n_packed += int(bool(g["res"].path_flags & 16))
         frame += 1
         if frame % 10 == 0:
             log.write(f"{frame} frames ok, {n_planes} slabs with band points, {n_found} planes found\n"); log.flush()
-print("ground fuzz: frames", frame, "slabs", n_planes, "planes found", n_found)
+print("ground fuzz: frames", frame, "slabs", n_planes, "planes found", n_found, "frames with packed survivors", n_packed)
