@@ -84,6 +84,20 @@ def test_bad_arguments_are_status_codes(lib):
     assert lib.cm_merge_voxelize(None, None, None) == capi.BAD_ARG
 
 
+def test_constants_mirror_the_header():
+    """Status codes, context flags and path flags of the ctypes binding against the #defines / enum of cloudmerge.h."""
+    text = open(HEADER).read()
+    defines = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"#define\s+(CM_\w+)\s+(0x[0-9a-fA-F]+|\d+)u?\b", text)}
+    enums = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(CM_[A-Z_]+)\s*=\s*(-?\d+)\s*,", text)}
+    for name in ("PROFILE", "LATEST_WINS", "OCCUPANCY"):
+        assert getattr(capi, "FLAG_" + name) == defines["CM_FLAG_" + name]
+    for name in ("LDS_RANK", "BUCKET", "PREDICTED", "REDONE", "PACKED"):
+        assert getattr(capi, "PATH_" + name) == defines["CM_PATH_" + name]
+    for name in ("OK", "EMPTY_INPUT", "GRID_OVERFLOW", "NOT_READY", "SKIPPED", "BAD_ARG", "CAPACITY"):
+        assert getattr(capi, name) == enums["CM_" + name]
+    assert capi.MAX_SENSORS == defines["CM_MAX_SENSORS"] and capi.NO_FIELD == defines["CM_NO_FIELD"]
+
+
 def test_scripts_compile():
     """The measurement and differential-run scripts under scripts/ are not imported by the suite (they need a GPU and
     minutes of time): at least keep them syntactically alive."""
