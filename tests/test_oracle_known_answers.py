@@ -74,3 +74,18 @@ def test_multithreaded_ingest_matches_serial():
     st6, m6, o6, rep = oracle.merge_voxelize(sensors, params, threads=6)
     assert st1 == st6 == oracle.OK and rep.threads_used == 4
     assert m1.tobytes() == m6.tobytes() and o1.tobytes() == o6.tobytes()
+
+
+def test_oracle_checksums_of_seeded_frames():
+    """tests/golden/oracle_checksums.json (make_oracle_checksums.py): the oracle's output for seeded synthetic frames must
+    not drift — neither through the oracle, nor the generators, nor the flags that decide fp32 results."""
+    import importlib.util
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_oracle_checksums", os.path.join(here, "make_oracle_checksums.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(here, "oracle_checksums.json")))
+    got = {name: mod.digest(*f) for name, f in mod.frames()}
+    assert got == want
