@@ -56,6 +56,9 @@ struct cm_ctx {
     uint32_t *hist = nullptr, *grp = nullptr, *totals = nullptr, *seg_counts = nullptr, *seg_tile_counts = nullptr, *seg_groups = nullptr;
     uint32_t cap_groups = 0, frame_seq = 0;
     bool lds_rank = false;               // k_probe_lds_order found lane-ordered LDS adds on this device
+    int finish_mode = 0;                 // CM_FINISH: 0 k3_local + k3_compact, 2 (CM_FINISH=v2) k2_local with its look-back
+    void* stage32 = nullptr;             // k3_local's staging for partial tables (32-byte entries)
+    int debug_misrank = 0;               // CM_DEBUG_MISRANK=1 (tests): the last global pass swaps two records of tile 0
     float* partials = nullptr;
     uint32_t *out_key = nullptr, *out_cnt = nullptr, *merged_total = nullptr;
     void* out = nullptr;
@@ -126,7 +129,7 @@ struct cm_ctx {
     uint32_t pre_bucket_backoff = 16;
     bool pre_bucket = false;             // this frame's outlier stage may sort with the bucket kernels
     bool last_packed = false;            // the voxel stage's k2_hist0 packed the survivors (CM_PATH_PACKED)
-    bool last_v2 = false, last_predicted = false;
+    bool last_v2 = false, last_predicted = false, last_k3 = false;
     bool post_bucket = false;            // the frame's pre-stages (ground / outlier removal) run first, then the bucket path
     uint32_t post_g = 0, post_low = 0;
     uint64_t last_n_merged = 0;          // points that entered the voxel grid in the last finished frame (0: none yet)
@@ -234,7 +237,7 @@ void free_all(cm_ctx* c) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(c->keys_a); F(c->keys_b); F(c->vals_a); F(c->vals_b); F(c->hist); F(c->totals);
     F(c->seg_counts); F(c->seg_tile_counts); F(c->seg_groups); F(c->grp); F(c->partials); F(c->out_key); F(c->out_cnt); F(c->merged_total); F(c->out); F(c->merged); F(c->partial); F(c->table_entries); F(c->mask); F(c->sorted_pts); F(c->rows); F(c->d_state_o);
-    F(c->rec_a); F(c->rec_b); F(c->dig); F(c->tile_state); F(c->wave_cnt); F(c->records);
+    F(c->stage32); F(c->rec_a); F(c->rec_b); F(c->dig); F(c->tile_state); F(c->wave_cnt); F(c->records);
     F(c->d_ground); F(c->d_state_g); F(c->gmask); F(c->zone_off); F(c->d_planes); F(c->hyp0); F(c->valid0); F(c->counts0); F(c->chunk_sums); F(c->bmask); F(c->zcode);
     F(c->d_frame); F(c->d_state[0]); F(c->d_state[1]);
     if (c->h_state) (void)hipHostFree(c->h_state);
@@ -474,10 +477,31 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
                      low_bits + 8 * pass, pass + 1 < n_global ? low_bits + 8 * (pass + 1) : 32u, nt, n_groups,
                      f.n_padded, c->records, nt, predicted ? 1 : 0, mask, 0, (pack && pass == 0) ? c->rec_b : nullptr, c->wave_cnt);
     }
-    prof_mark(c, "k2_local");
-    cmk2_local(st, c->d_frame, state, state_next, c->h_state_dev, ((n_global - 1) & 1u) ? c->rec_b : c->rec_a,
-               c->tile_state, reinterpret_cast<uint32_t*>(c->tile_state + (f.n_padded / 1024 + 1)), c->out, c->out_key,
-               c->out_cnt, mode == 1 ? c->partial : nullptr, low_bits, f.n_padded);
+    const void* rec_sorted = ((n_global - 1) & 1u) ? c->rec_b : c->rec_a;
+    c->last_k3 = c->finish_mode != 2;
+    if (c->last_k3) {
+        // k3_local stages every tile's centroids in the record buffer the last pass read from (dead by now), at the
+        // tile's own place; k3_compact moves them to `out`. Cells and counts (CM_FLAG_OCCUPANCY) ride in the general
+        // path's key / value arrays, which the bucket path does not use.
+        void* stage = ((n_global - 1) & 1u) ? c->rec_a : c->rec_b;
+        if (mode == 1) {
+            if (!c->stage32) HIP_TRY(c, hipMalloc(&c->stage32, static_cast<size_t>(c->cap_padded) * 32));
+            stage = c->stage32;
+        }
+        uint32_t* grp_cnt = reinterpret_cast<uint32_t*>(c->tile_state + f.n_padded / 2048);
+        uint32_t* skey = c->out_key ? c->keys_a : nullptr;
+        prof_mark(c, "k3_local");
+        cmk3_local(st, c->d_frame, state, c->h_state_dev, rec_sorted, c->tile_state, grp_cnt, stage, skey, c->vals_a, mode == 1,
+                   low_bits, f.n_padded);
+        prof_mark(c, "k3_compact");
+        cmk3_compact(st, state, state_next, c->h_state_dev, c->tile_state, grp_cnt, stage, skey, c->vals_a,
+                     mode == 1 ? c->partial : c->out, c->out_key, c->out_cnt, mode == 1, f.n_padded);
+    } else {
+        prof_mark(c, "k2_local");
+        cmk2_local(st, c->d_frame, state, state_next, c->h_state_dev, rec_sorted,
+                   c->tile_state, reinterpret_cast<uint32_t*>(c->tile_state + (f.n_padded / 1024 + 1)), c->out, c->out_key,
+                   c->out_cnt, mode == 1 ? c->partial : nullptr, low_bits, f.n_padded);
+    }
     prof_mark(c, "end");
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_done, st));
@@ -824,8 +848,12 @@ int wait_frame(cm_ctx* c, cm_result* res) {
             // bucket did not fit LDS, or when a workgroup gave up waiting for its predecessors: the
             // classic path redoes it (the sensors' clouds are still in place) and the cause is dealt with.
             const CmFrameState& h0 = *c->h_state;
-            if (h0.outside || h0.err == CM_DEV_ERR_BUCKET || h0.err == CM_DEV_ERR_BUCKET_PRE || h0.err == CM_DEV_ERR_LOOKBACK) {
+            if (h0.outside || h0.err == CM_DEV_ERR_BUCKET || h0.err == CM_DEV_ERR_BUCKET_PRE || h0.err == CM_DEV_ERR_LOOKBACK ||
+                h0.err == CM_DEV_ERR_UNSORTED) {
                 if (h0.outside) c->pred_ok = false;
+                // The finish found records out of bucket order: a global pass mis-ranked. Stop trusting lane-ordered LDS adds
+                // on this device (the general path then ranks by ballots, and the bucket path, which needs them, stays off).
+                if (h0.err == CM_DEV_ERR_UNSORTED) { c->lds_rank = false; c->h_state->err = 0; }
                 if (h0.err == CM_DEV_ERR_BUCKET) {
                     if (c->v2_extra_passes < CM_MAX_PASSES) ++c->v2_extra_passes;
                     if (c->v2_good_frames < 8 && c->v2_retry_after < (1u << 20)) c->v2_retry_after *= 2;   // the retry failed at once
@@ -899,7 +927,7 @@ int wait_frame(cm_ctx* c, cm_result* res) {
         r.key_bits = h.key_bits;
         r.sort_passes = h.n_passes;
         r.path_flags = (c->lds_rank ? 1u : 0u) | (c->last_v2 ? 2u : 0u) | (c->last_predicted ? 4u : 0u) | (redone ? 8u : 0u) |
-                       ((c->last_v2 && c->last_packed) ? 16u : 0u);
+                       ((c->last_v2 && c->last_packed) ? 16u : 0u) | ((c->last_v2 && c->last_k3) ? 32u : 0u);
         if (c->last_predicted && h.status == CM_OK) {
             // The device sorted by cells of the predicted box (same order); the grid PCL itself would
             // report comes from the cloud's exact bounds, which the frame also produced (A.4 steps 2, 4).
@@ -1041,6 +1069,8 @@ int cm_create(cm_ctx** out, int device, const cm_limits* lim) {
             c->lds_rank = ok && violations == 0;
         }
     }
+    if (const char* fm = getenv("CM_FINISH")) c->finish_mode = std::strcmp(fm, "v2") == 0 ? 2 : 0;
+    if (const char* dm = getenv("CM_DEBUG_MISRANK")) c->debug_misrank = dm[0] == '1' ? 1 : 0;
     if (!ok) {
         free_all(c);
         delete c;

@@ -63,6 +63,15 @@ void cmk2_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameSt
 void cmk2_local_sort(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* host_state, const void* rec,
                      uint32_t* keys_sorted, void* recs_sorted, uint32_t low_bits, uint32_t n_padded);
 
+// ---- voxel finish of the bucket path, second generation (cm_kernels_v3.hip): k3_local + k3_compact
+// tile_info: one uint2 per 2048-record tile; grp_cnt: one zeroed word per 64 tiles; stage: 16 B (32 B: partial) per record slot
+void cmk3_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* host_state, const void* rec, void* tile_info,
+                uint32_t* grp_cnt, void* stage, uint32_t* stage_key, uint32_t* stage_cnt, bool partial, uint32_t low_bits,
+                uint32_t n_padded);
+void cmk3_compact(hipStream_t s, const CmFrameState* st, CmFrameState* st_next, uint32_t* host_state, const void* tile_info,
+                  const uint32_t* grp_cnt, const void* stage, const uint32_t* stage_key, const uint32_t* stage_cnt, void* out,
+                  uint32_t* out_key, uint32_t* out_cnt, bool partial, uint32_t n_padded);
+
 // ---- zone-wise ground removal (cm_kernels_ground.hip) ------------------------------------------
 void cmkg_setup(hipStream_t s, const CmGroundDev& g, CmGroundDev* d_ground);
 void cmkg_classify(hipStream_t s, const CmFrameDev* fd, const CmGroundDev* gd, CmFrameState* st, uint32_t* keys,

@@ -109,6 +109,8 @@ typedef struct cm_result {
                                   checked against it, min_b/max_b/div_b/min_p/max_p are the cloud's own */
 #define CM_PATH_PACKED 16u    /* bucket path, crop box that dropped most of the last frame's points: the survivors' records were
                                   packed while counting, so the raw clouds were read once instead of twice */
+#define CM_PATH_SPLIT 32u      /* bucket path, finish by k3_local + k3_compact (tiles stage their centroids, a second launch
+                                  packs them: no look-back between tiles); otherwise k2_local */
 #define CM_PATH_REDONE 8u      /* the bucket path gave the frame back (a point outside the predicted box, or a
                                   bucket too large for LDS) and the general path computed it */
 

@@ -91,7 +91,7 @@ def test_constants_mirror_the_header():
     enums = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(CM_[A-Z_]+)\s*=\s*(-?\d+)\s*,", text)}
     for name in ("PROFILE", "LATEST_WINS", "OCCUPANCY"):
         assert getattr(capi, "FLAG_" + name) == defines["CM_FLAG_" + name]
-    for name in ("LDS_RANK", "BUCKET", "PREDICTED", "REDONE", "PACKED"):
+    for name in ("LDS_RANK", "BUCKET", "PREDICTED", "REDONE", "PACKED", "SPLIT"):
         assert getattr(capi, "PATH_" + name) == defines["CM_PATH_" + name]
     for name in ("OK", "EMPTY_INPUT", "GRID_OVERFLOW", "NOT_READY", "SKIPPED", "BAD_ARG", "CAPACITY"):
         assert getattr(capi, name) == enums["CM_" + name]
