@@ -72,6 +72,7 @@ struct cm_ctx {
     void* table_entries = nullptr;       // merged entries inside cm_merge_tables
     int last_mode = 0;
     CmFrameDev* d_frame = nullptr;
+    CmTileDev* d_tiles = nullptr;        // per-tile entries of the uploaded descriptor (k_setup)
     CmFrameDev frame_uploaded;
     bool frame_uploaded_valid = false;
     CmFrameState* d_state[2] = {nullptr, nullptr};
@@ -239,7 +240,7 @@ void free_all(cm_ctx* c) {
     F(c->seg_counts); F(c->seg_tile_counts); F(c->seg_groups); F(c->grp); F(c->partials); F(c->out_key); F(c->out_cnt); F(c->merged_total); F(c->out); F(c->merged); F(c->partial); F(c->table_entries); F(c->mask); F(c->sorted_pts); F(c->rows); F(c->d_state_o);
     F(c->stage32); F(c->rec_a); F(c->rec_b); F(c->dig); F(c->tile_state); F(c->wave_cnt); F(c->records);
     F(c->d_ground); F(c->d_state_g); F(c->gmask); F(c->zone_off); F(c->d_planes); F(c->hyp0); F(c->valid0); F(c->counts0); F(c->chunk_sums); F(c->bmask); F(c->zcode);
-    F(c->d_frame); F(c->d_state[0]); F(c->d_state[1]);
+    F(c->d_frame); F(c->d_tiles); F(c->d_state[0]); F(c->d_state[1]);
     if (c->h_state) (void)hipHostFree(c->h_state);
     for (auto& s : c->slots) {
         F(s.dbuf);
@@ -371,7 +372,7 @@ int bootstrap_box(cm_ctx* c) {
     const CmFrameDev& f = c->frame;
     hipStream_t st = c->stream;
     if (!c->frame_uploaded_valid || std::memcmp(&f, &c->frame_uploaded, sizeof f) != 0) {
-        cmk_setup(st, f, c->d_frame);
+        cmk_setup(st, f, c->d_frame, c->d_tiles);
         c->frame_uploaded = f;
         c->frame_uploaded_valid = true;
     }
@@ -440,7 +441,7 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
     { const int e = bucket_buffers(c); if (e != CM_OK) return e; }
     if (!c->frame_uploaded_valid || std::memcmp(&f, &c->frame_uploaded, sizeof f) != 0) {
         prof_mark(c, "k_setup");
-        cmk_setup(st, f, c->d_frame);
+        cmk_setup(st, f, c->d_frame, c->d_tiles);
         c->frame_uploaded = f;
         c->frame_uploaded_valid = true;
     }
@@ -463,7 +464,7 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
     const bool pack = !predicted && pack_survivors(c);
     c->last_packed = pack;
     prof_mark(c, "k2_hist0");
-    cmk2_hist0(st, c->d_frame, state, c->hist, grp0, grp0_next, c->grp + 2 * gstride, gw, static_cast<uint32_t>(gstride),
+    cmk2_hist0(st, c->d_frame, c->d_tiles, state, c->hist, grp0, grp0_next, c->grp + 2 * gstride, gw, static_cast<uint32_t>(gstride),
                c->tile_state, f.n_padded / 1024 + 2, c->records, grid_mode, predicted ? 1 : 0, low_bits, n_global, nt, mask,
                st_outlier, 0, pack ? c->rec_b : nullptr, c->wave_cnt);
     for (uint32_t pass = 0; pass < n_global; ++pass) {
@@ -473,7 +474,7 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
         prof_mark(c, "k2_scatter");
         const void* in = (pass & 1u) ? c->rec_a : c->rec_b;
         void* out = (pass & 1u) ? c->rec_b : c->rec_a;
-        cmk2_scatter(st, pass == 0, c->d_frame, state, in, out, c->dig, c->hist, grp, big ? c->totals : nullptr,
+        cmk2_scatter(st, pass == 0, c->d_frame, c->d_tiles, state, in, out, c->dig, c->hist, grp, big ? c->totals : nullptr,
                      low_bits + 8 * pass, pass + 1 < n_global ? low_bits + 8 * (pass + 1) : 32u, nt, n_groups,
                      f.n_padded, c->records, nt, predicted ? 1 : 0, mask, 0, (pack && pass == 0) ? c->rec_b : nullptr, c->wave_cnt);
     }
@@ -646,7 +647,7 @@ int launch_classic(cm_ctx* c, const cm_params* p, int mode, int grid_mode, uint3
     hipStream_t st = c->stream;
     if (!c->frame_uploaded_valid || std::memcmp(&f, &c->frame_uploaded, sizeof f) != 0) {
         prof_mark(c, "k_setup");
-        cmk_setup(st, f, c->d_frame);
+        cmk_setup(st, f, c->d_frame, c->d_tiles);
         c->frame_uploaded = f;
         c->frame_uploaded_valid = true;
     }
@@ -713,7 +714,7 @@ int launch_classic(cm_ctx* c, const cm_params* p, int mode, int grid_mode, uint3
             ++c->frame_seq;
             const bool pack = pack_survivors(c);
             prof_mark(c, "k2_hist0(outlier)");
-            cmk2_hist0(st, c->d_frame, c->d_state_o, c->hist, grp0, grp0_next, c->grp + 2 * gstride, gw, static_cast<uint32_t>(gstride),
+            cmk2_hist0(st, c->d_frame, c->d_tiles, c->d_state_o, c->hist, grp0, grp0_next, c->grp + 2 * gstride, gw, static_cast<uint32_t>(gstride),
                        c->tile_state, f.n_padded / 1024 + 2, c->records, 1, 0, low, g, nt, in, nullptr, 1,
                        pack ? c->rec_b : nullptr, c->wave_cnt);
             for (uint32_t pass = 0; pass < g; ++pass) {
@@ -721,7 +722,7 @@ int launch_classic(cm_ctx* c, const cm_params* p, int mode, int grid_mode, uint3
                 if (pass > 0) { prof_mark(c, "k2_hist"); cmk2_hist(st, c->d_state_o, c->dig, c->hist, grp, nt); }
                 if (big) { prof_mark(c, "k_gscan"); cmk_gscan(st, c->d_state_o, grp, c->totals, pass, n_groups); }
                 prof_mark(c, "k2_scatter(outlier)");
-                cmk2_scatter(st, pass == 0, c->d_frame, c->d_state_o, (pass & 1u) ? c->rec_a : c->rec_b, (pass & 1u) ? c->rec_b : c->rec_a,
+                cmk2_scatter(st, pass == 0, c->d_frame, c->d_tiles, c->d_state_o, (pass & 1u) ? c->rec_a : c->rec_b, (pass & 1u) ? c->rec_b : c->rec_a,
                              c->dig, c->hist, grp, big ? c->totals : nullptr, low + 8 * pass, pass + 1 < g ? low + 8 * (pass + 1) : 32u,
                              nt, n_groups, f.n_padded, c->records, nt, 0, in, 1, (pack && pass == 0) ? c->rec_b : nullptr, c->wave_cnt);
             }
@@ -1042,6 +1043,7 @@ int cm_create(cm_ctx** out, int device, const cm_limits* lim) {
     if (c->flags & CM_FLAG_OCCUPANCY)
         ok = ok && A(reinterpret_cast<void**>(&c->out_key), n4) && A(reinterpret_cast<void**>(&c->out_cnt), n4);
     ok = ok && A(reinterpret_cast<void**>(&c->d_frame), sizeof(CmFrameDev));
+    ok = ok && A(reinterpret_cast<void**>(&c->d_tiles), static_cast<size_t>(c->cap_tiles) * sizeof(CmTileDev));
     ok = ok && A(reinterpret_cast<void**>(&c->d_state[0]), sizeof(CmFrameState));
     ok = ok && A(reinterpret_cast<void**>(&c->d_state[1]), sizeof(CmFrameState));
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_state), sizeof(CmFrameState), hipHostMallocDefault) == hipSuccess;
@@ -1351,7 +1353,7 @@ int cm_local_bounds(cm_ctx* c, const cm_params* p, float min_xyz[3], float max_x
     if (n_valid) *n_valid = 0;
     const CmFrameDev& f = c->frame;
     if (f.n_padded == 0) return CM_OK;
-    cmk_setup(c->stream, f, c->d_frame);
+    cmk_setup(c->stream, f, c->d_frame, c->d_tiles);
     c->frame_uploaded = f;
     c->frame_uploaded_valid = true;
     const uint32_t n_partials = f.n_tiles < CM_MINMAX_BLOCKS ? f.n_tiles : CM_MINMAX_BLOCKS;
@@ -1460,7 +1462,7 @@ int cm_merge_tables(cm_ctx* c, const void* const* dev_tables, const uint64_t* n_
         return r.status;
     }
     hipStream_t st = c->stream;
-    cmk_setup(st, f, c->d_frame);
+    cmk_setup(st, f, c->d_frame, c->d_tiles);
     c->frame_uploaded = f;
     c->frame_uploaded_valid = true;
     CmFrameState* state = c->d_state[c->cur];

@@ -173,6 +173,31 @@ __device__ __forceinline__ void load_tile_points(const CmSensorDev& sd, uint32_t
     }
 }
 
+// The same from a tile entry (k_setup): `first` counts from the tile's first point.
+template <int LAYOUT, int N>
+__device__ __forceinline__ void load_tile_raw(const unsigned char* __restrict__ data, uint32_t n, uint32_t step, uint32_t ox,
+                                              uint32_t oy, uint32_t oz, uint32_t oi, uint32_t first, Pt (&p)[N]) {
+    const float nan = __uint_as_float(0x7FC00000u);
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        const uint32_t i = first + r * 64;
+        p[r] = load_point(data, LAYOUT, step, ox, oy, oz, oi, i < n ? i : n - 1);
+    }
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        const bool ok = first + r * 64 < n;
+        p[r].x = ok ? p[r].x : nan; p[r].y = ok ? p[r].y : nan; p[r].z = ok ? p[r].z : nan;
+        p[r].i = ok ? p[r].i : 0.f;
+    }
+}
+template <int N>
+__device__ __forceinline__ void load_tile_te(const CmTileDev& te, const CmSensorDev& sd, uint32_t first, Pt (&p)[N]) {
+    const uint32_t layout = te.info >> 8;
+    if (layout == CM_LAYOUT_XYZI16) load_tile_raw<CM_LAYOUT_XYZI16, N>(te.data, te.n_left, 16u, 0u, 4u, 8u, 12u, first, p);
+    else if (layout == CM_LAYOUT_PCL32) load_tile_raw<CM_LAYOUT_PCL32, N>(te.data, te.n_left, 32u, 0u, 4u, 8u, 16u, first, p);
+    else load_tile_raw<CM_LAYOUT_GENERIC, N>(te.data, te.n_left, sd.point_step, sd.off_x, sd.off_y, sd.off_z, sd.off_i, first, p);
+}
+
 // N points of one lane, 64 apart (wave-striped), starting at index `first` of the sensor's cloud.
 template <int N>
 __device__ __forceinline__ void load_tile(const CmSensorDev& sd, uint32_t first, Pt (&p)[N]) {

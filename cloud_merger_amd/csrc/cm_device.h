@@ -51,6 +51,15 @@ struct CmSensorDev {
     uint32_t _pad;
 };
 
+// One entry per 4096-slot tile of the padded index space, written by k_setup with the frame descriptor: where the
+// tile's first point lies and how many points of its cloud are left from there, so that the streaming kernels reach
+// their points through ONE dependent load instead of descriptor -> sensor -> payload.
+struct CmTileDev {
+    const unsigned char* data;   // address of the tile's first point
+    uint32_t n_left;             // points of the cloud from there to its end (>= 1)
+    uint32_t info;               // index into CmFrameDev::s | layout << 8
+};
+
 struct CmFrameDev {
     CmSensorDev s[CM_DEV_MAX_SENSORS];
     uint32_t n_sensors;

@@ -5,7 +5,7 @@
 
 #include "cm_device.h"
 
-void cmk_setup(hipStream_t s, const CmFrameDev& f, CmFrameDev* d_frame);
+void cmk_setup(hipStream_t s, const CmFrameDev& f, CmFrameDev* d_frame, CmTileDev* d_tiles);   // d_tiles: cap_tiles entries, or nullptr
 void cmk_minmax(hipStream_t s, const CmFrameDev* fd, float* partials, uint32_t n_blocks, const unsigned char* mask);
 void cmk_keys(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* keys, uint32_t* hist,
               uint32_t* grp_acc, uint32_t* grp_clear_a, uint32_t* grp_clear_b, uint32_t n_group_words,
@@ -44,14 +44,14 @@ void cmk_merged(hipStream_t s, const CmFrameDev* fd, uint32_t* tile_counts, uint
                 uint32_t n_tiles, const unsigned char* mask);
 
 // ---- bucket path (cm_kernels_v2.hip) --------------------------------------------------------
-void cmk2_hist0(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* hist, uint32_t* grp_acc,
+void cmk2_hist0(hipStream_t s, const CmFrameDev* fd, const CmTileDev* tiles, CmFrameState* st, uint32_t* hist, uint32_t* grp_acc,
                 uint32_t* grp_clear_a, uint32_t* grp_clear_b, uint32_t n_group_words, uint32_t n_clear_a_words,
                 unsigned long long* tile_state, uint32_t n_tile_state, float* records, int grid_mode, int check_box,
                 uint32_t shift0, uint32_t n_global_passes, uint32_t n_tiles, const unsigned char* mask,
                 const CmFrameState* st_outlier, int use_cell = 0, void* compact_out = nullptr, uint32_t* wave_cnt = nullptr);
 void cmk2_hist(hipStream_t s, const CmFrameState* st, const unsigned char* dig, uint32_t* hist, uint32_t* grp,
                uint32_t n_tiles);
-void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, CmFrameState* st, const void* rec_in, void* rec_out,
+void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, const CmTileDev* tiles, CmFrameState* st, const void* rec_in, void* rec_out,
                   unsigned char* dig_out, const uint32_t* hist, const uint32_t* grp, const uint32_t* totals,
                   uint32_t shift, uint32_t next_shift, uint32_t n_tiles, uint32_t n_groups, uint32_t n_padded,
                   const float* records, uint32_t n_records, int fold, const unsigned char* mask, int use_cell = 0,

@@ -30,8 +30,21 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // k_setup: upload the frame descriptor (passed by value) into HBM.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_setup(CmFrameDev f, CmFrameDev* __restrict__ dst) {
+__global__ void k_setup(CmFrameDev f, CmFrameDev* __restrict__ dst, CmTileDev* __restrict__ tiles) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *dst = f;
+    const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tiles && tile < f.n_tiles) {
+        const uint32_t first = tile * CM_TILE;
+        uint32_t k = 0;
+        for (uint32_t q = 1; q < f.n_sensors; ++q) k += (first >= f.s[q].base) ? 1u : 0u;
+        const CmSensorDev& sd = f.s[k];
+        CmTileDev te;
+        const uint32_t off = first - sd.base;
+        te.data = sd.data + static_cast<size_t>(off) * sd.point_step;
+        te.n_left = sd.n > off ? sd.n - off : 0u;
+        te.info = k | (sd.layout << 8);
+        tiles[tile] = te;
+    }
 }
 
 
@@ -1259,8 +1272,8 @@ __global__ __launch_bounds__(CM_BLOCK) void k_merged_write(const CmFrameDev* __r
 #define CM_LAUNCH(kernel, grid, block, stream, ...) \
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
 
-void cmk_setup(hipStream_t s, const CmFrameDev& f, CmFrameDev* d_frame) {
-    CM_LAUNCH(k_setup, 1, 64, s, f, d_frame);
+void cmk_setup(hipStream_t s, const CmFrameDev& f, CmFrameDev* d_frame, CmTileDev* d_tiles) {
+    CM_LAUNCH(k_setup, d_tiles ? (f.n_tiles + 255) / 256 + (f.n_tiles == 0) : 1, d_tiles ? 256 : 64, s, f, d_frame, d_tiles);
 }
 void cmk_minmax(hipStream_t s, const CmFrameDev* fd, float* partials, uint32_t n_blocks, const unsigned char* mask) {
     CM_LAUNCH(k_minmax, n_blocks, CM_BLOCK, s, fd, partials, mask);

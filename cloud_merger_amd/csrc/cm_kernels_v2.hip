@@ -120,6 +120,7 @@ __device__ __forceinline__ uint32_t sensor_of_slot(const CmFrameDev* __restrict_
 // ------------------------------------------------------------------------------------------------
 template <bool PACK>
 __global__ __launch_bounds__(CM2_BLOCK, PACK ? 8 : 1) void k2_hist0(const CmFrameDev* __restrict__ fd,
+                                                      const CmTileDev* __restrict__ tiles,
                                                       CmFrameState* __restrict__ st,
                                                       uint32_t* __restrict__ hist,
                                                       uint32_t* __restrict__ grp_acc,
@@ -163,13 +164,14 @@ __global__ __launch_bounds__(CM2_BLOCK, PACK ? 8 : 1) void k2_hist0(const CmFram
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t slot0 = tile * CM_TILE + w * (64 * CM2_ITEMS) + lane;
-    const CmSensorDev& sd = fd->s[sensor_of_slot(fd, tile * CM_TILE)];
+    const CmTileDev te = tiles[tile];                     // (one dependent load to the tile's points; the matrix comes meanwhile)
+    const CmSensorDev& sd = fd->s[te.info & 0xFFu];
+    Pt p[CM2_ITEMS];
+    load_tile_te<CM2_ITEMS>(te, sd, w * (64 * CM2_ITEMS) + lane, p);
     float m[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) m[k] = sd.m[k];
     const uint32_t crop = fd->crop_enable;
-    Pt p[CM2_ITEMS];
-    load_tile<CM2_ITEMS>(sd, slot0 - sd.base, p);
     if (threadIdx.x < CM_RADIX) lh[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_out = 0;
     __syncthreads();
@@ -271,6 +273,16 @@ __global__ __launch_bounds__(CM2_BLOCK) void k2_hist(const CmFrameState* __restr
     }
 }
 
+// Phase timing of the local finish (scripts/phase_times.py; build with CM_PHASE_TIMING=1): thread 0 of every
+// workgroup stores the 100 MHz ticks between phase boundaries. Compiled out of the product build.
+#ifdef CM_PHASE_TIMING
+__device__ unsigned long long g_phase[4096 * 16];
+#define PH_START() long long t0_ = wall_clock64()
+#define PH(k) do { if (threadIdx.x == 0) { const long long t1_ = wall_clock64(); g_phase[(blockIdx.x & 4095) * 16 + (k)] = (unsigned long long)(t1_ - t0_); t0_ = t1_; } } while (0)
+#else
+#define PH_START() do {} while (0)
+#define PH(k) do {} while (0)
+#endif
 // ------------------------------------------------------------------------------------------------
 // k2_scatter: stable scatter of one 4096-record tile by one 8-bit digit; the record itself moves.
 // FIRST: reads the raw sensor points (transform + crop once more, dropping invalid slots: this is
@@ -279,7 +291,8 @@ __global__ __launch_bounds__(CM2_BLOCK) void k2_hist(const CmFrameState* __restr
 // selected after the device probe passed).
 // ------------------------------------------------------------------------------------------------
 template <bool FIRST>
-__global__ __launch_bounds__(CM2_BLOCK, 3) void k2_scatter(const CmFrameDev* __restrict__ fd,
+__global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __restrict__ fd,
+                                                           const CmTileDev* __restrict__ tiles,
                                                            CmFrameState* __restrict__ st,
                                                            const float4* __restrict__ rec_in,
                                                            float4* __restrict__ rec_out,
@@ -294,12 +307,16 @@ __global__ __launch_bounds__(CM2_BLOCK, 3) void k2_scatter(const CmFrameDev* __r
                                                            const unsigned char* __restrict__ mask, int use_cell,
                                                            const float4* __restrict__ compact_in,
                                                            const uint32_t* __restrict__ wave_cnt) {
-    __shared__ float4 srec[CM_TILE / 2];                // staging in two halves: 41 KB per workgroup, three per CU
-    __shared__ uint32_t whist[CM2_WAVES][CM_RADIX];
+    // 37 KB of LDS and at most 64 VGPRs: four workgroups per CU, so that the 977 tiles of a 4 M-point frame are all
+    // resident at once (with three per CU the last 209 tiles ran as a second, nearly empty generation)
+    __shared__ float4 srec[CM_TILE / 2];                // staging in two halves
+    __shared__ uint32_t whist[CM2_WAVES][CM_RADIX / 2]; // digit counts per wave, two 16-bit counters per word (a wave ranks 512 records)
     __shared__ uint32_t gofs[CM_RADIX];
+    __shared__ uint16_t s_dbase[CM_RADIX];
     __shared__ uint32_t lds[CM2_WAVES];
     __shared__ uint32_t s_tile_valid;
     if (st->status != CM_DEV_OK || st->outside) return;
+    PH_START();
     uint32_t tile = blockIdx.x;
     {
         const uint32_t per = gridDim.x / 8;              // contiguous tile range per XCD (see k_scatter)
@@ -310,9 +327,45 @@ __global__ __launch_bounds__(CM2_BLOCK, 3) void k2_scatter(const CmFrameDev* __r
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t first = tile * CM_TILE + w * (64 * CM2_ITEMS) + lane;
 
+    // Records of digit d written before this tile's: the totals of the groups before its group (threads 0-255, one
+    // digit each) and the counts of the tiles before it in its group (threads 256-511), every load of a thread in
+    // flight at once and asked for before the tile's records, so that the latencies overlap (summed one batch after
+    // the other behind the finished record loads they were 39 % of a tile's time; asking for the records first and
+    // for these behind them was slower still: 94 spilled registers in the first pass).
+    const uint32_t grp_id = tile / CM_GROUP;
+    uint32_t before = 0, my_total = 0;
+    {
+        const uint32_t d = threadIdx.x & (CM_RADIX - 1);
+        if (threadIdx.x < CM_RADIX) {
+            if (totals) {
+                my_total = totals[d];
+                before = grp[static_cast<size_t>(grp_id) * CM_RADIX + d];
+            } else {
+                for (uint32_t g = 0; g < n_groups; g += 16) {
+                    uint32_t v[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) v[q] = (g + q < n_groups) ? grp[static_cast<size_t>(g + q) * CM_RADIX + d] : 0u;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) { my_total += v[q]; before += (g + q < grp_id) ? v[q] : 0u; }
+                }
+            }
+        } else {
+            for (uint32_t t = grp_id * CM_GROUP; t < tile; t += 16) {
+                uint32_t v[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) v[q] = (t + q < tile) ? hist[static_cast<size_t>(t + q) * CM_RADIX + d] : 0u;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) before += v[q];
+            }
+            gofs[d] = before;                                  // (picked up by thread d behind the barriers of the scans below)
+        }
+    }
+
     float4 rec[CM2_ITEMS];
-    uint32_t key[CM2_ITEMS];
+    uint32_t lp[CM2_ITEMS];                               // digit, then digit | rank << 16, then the position in the sorted tile
     uint32_t vmask = 0;
+    Pt p[CM2_ITEMS];                                      // (first pass: the raw points)
+    uint32_t sidx = 0;
     if (FIRST && compact_in) {
         // k2_hist0 left this tile's surviving records packed per wave, in slot order: same (wave, round, lane) layout
         // as the raw read below, so the ranking stays stable; nothing to transform or to test again.
@@ -326,31 +379,13 @@ __global__ __launch_bounds__(CM2_BLOCK, 3) void k2_scatter(const CmFrameDev* __r
         for (int r = 0; r < CM2_ITEMS; ++r) {
             const uint32_t i = r * 64 + lane;
             rec[r] = src[i < cw ? i : 0u];                 // (unconditional load; slot 0 of the wave's range is always mapped)
-            key[r] = key_of(b, rec[r]);
+            lp[r] = (key_of(b, rec[r]) >> shift) & (CM_RADIX - 1);
             if (i < cw) vmask |= 1u << r;
         }
     } else if (FIRST) {
-        const CmSensorDev& sd = fd->s[sensor_of_slot(fd, tile * CM_TILE)];
-        float m[12];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) m[k] = sd.m[k];
-        const uint32_t crop = fd->crop_enable;
-        const bool all_fields = fd->downsample_all != 0;
-        Pt p[CM2_ITEMS];
-        load_tile<CM2_ITEMS>(sd, first - sd.base, p);
-#pragma unroll
-        for (int r = 0; r < CM2_ITEMS; ++r) {
-            rec[r].x = xf_row(m[0], m[1], m[2], m[3], p[r].x, p[r].y, p[r].z);
-            rec[r].y = xf_row(m[4], m[5], m[6], m[7], p[r].x, p[r].y, p[r].z);
-            rec[r].z = xf_row(m[8], m[9], m[10], m[11], p[r].x, p[r].y, p[r].z);
-            rec[r].w = use_cell ? __uint_as_float(first + r * 64) : (all_fields ? p[r].i : 0.f);   // outlier stage: the point's padded index rides along
-            bool in = false;
-            key[r] = 0;
-            if (point_valid(rec[r].x, rec[r].y, rec[r].z, crop, fd->crop_min, fd->crop_max) &&
-                (!mask || mask[first + r * 64]))
-                key[r] = key_of(b, rec[r].x, rec[r].y, rec[r].z, &in);
-            if (in) vmask |= 1u << r;
-        }
+        const CmTileDev te = tiles[tile];
+        sidx = te.info & 0xFFu;
+        load_tile_te<CM2_ITEMS>(te, fd->s[sidx], w * (64 * CM2_ITEMS) + lane, p);
     } else {
 #pragma unroll
         for (int r = 0; r < CM2_ITEMS; ++r) {
@@ -359,91 +394,96 @@ __global__ __launch_bounds__(CM2_BLOCK, 3) void k2_scatter(const CmFrameDev* __r
         }
     }
 
-    // Records of digit d written before this tile's (thread d < 256), as in k_scatter.
-    const uint32_t grp_id = tile / CM_GROUP;
-    uint32_t before = 0, my_total = 0;
-    if (threadIdx.x < CM_RADIX) {
-        if (totals) {
-            my_total = totals[threadIdx.x];
-            before = grp[static_cast<size_t>(grp_id) * CM_RADIX + threadIdx.x];
-        } else {
-            for (uint32_t g = 0; g < n_groups; g += 16) {
-                uint32_t v[16];
+    if (FIRST && !compact_in) {
+        const CmSensorDev& sd = fd->s[sidx];
+        float m[12];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) v[q] = (g + q < n_groups) ? grp[static_cast<size_t>(g + q) * CM_RADIX + threadIdx.x] : 0u;
+        for (int k = 0; k < 12; ++k) m[k] = sd.m[k];
+        const uint32_t crop = fd->crop_enable;
+        const bool all_fields = fd->downsample_all != 0;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) { my_total += v[q]; before += (g + q < grp_id) ? v[q] : 0u; }
-            }
-        }
-        const uint32_t t0 = grp_id * CM_GROUP;
-        for (uint32_t t = t0; t < tile; t += 16) {
-            uint32_t v[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] = (t + q < tile) ? hist[static_cast<size_t>(t + q) * CM_RADIX + threadIdx.x] : 0u;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) before += v[q];
+        for (int r = 0; r < CM2_ITEMS; ++r) {
+            rec[r].x = xf_row(m[0], m[1], m[2], m[3], p[r].x, p[r].y, p[r].z);
+            rec[r].y = xf_row(m[4], m[5], m[6], m[7], p[r].x, p[r].y, p[r].z);
+            rec[r].z = xf_row(m[8], m[9], m[10], m[11], p[r].x, p[r].y, p[r].z);
+            rec[r].w = use_cell ? __uint_as_float(first + r * 64) : (all_fields ? p[r].i : 0.f);   // outlier stage: the point's padded index rides along
+            bool in = false;
+            lp[r] = 0;
+            if (point_valid(rec[r].x, rec[r].y, rec[r].z, crop, fd->crop_min, fd->crop_max) &&
+                (!mask || mask[first + r * 64]))
+                lp[r] = (key_of(b, rec[r].x, rec[r].y, rec[r].z, &in) >> shift) & (CM_RADIX - 1);
+            if (in) vmask |= 1u << r;
         }
     }
+
+    PH((FIRST ? 0 : 8) + 0);
     uint32_t gtot;
     const uint32_t gbase = block_excl_scan_w<CM2_WAVES>(my_total, lds, &gtot);
     if (FIRST && tile == 0 && threadIdx.x == 0) st->n_valid = gtot;
     const uint32_t n = FIRST ? n_padded : gtot;
     if (tile * CM_TILE >= n) return;                     // uniform (n is the same in every workgroup)
+    PH((FIRST ? 0 : 8) + 1);
 
     if (!FIRST) {
 #pragma unroll
         for (int r = 0; r < CM2_ITEMS; ++r) {
-            key[r] = key_of(b, rec[r]);
+            lp[r] = (key_of(b, rec[r]) >> shift) & (CM_RADIX - 1);
             if (first + r * 64 < n) vmask |= 1u << r;
         }
     }
-#pragma unroll
-    for (int q = 0; q < CM2_WAVES; ++q)
-        if (threadIdx.x < CM_RADIX) whist[q][threadIdx.x] = 0;
+    for (uint32_t q = threadIdx.x; q < CM2_WAVES * CM_RADIX / 2; q += CM2_BLOCK) (&whist[0][0])[q] = 0;
     __syncthreads();
-    uint32_t rank[CM2_ITEMS];
 #pragma unroll
     for (int r = 0; r < CM2_ITEMS; ++r) {
-        const uint32_t digit = (key[r] >> shift) & (CM_RADIX - 1);
-        rank[r] = (vmask >> r & 1u) ? atomicAdd(&whist[w][digit], 1u) : 0u;
+        const uint32_t sh = (lp[r] & 1u) * 16u;
+        if (vmask >> r & 1u) lp[r] |= ((atomicAdd(&whist[w][lp[r] >> 1], 1u << sh) >> sh) & 0xFFFFu) << 16;
     }
     __syncthreads();
+    PH((FIRST ? 0 : 8) + 2);
     {
-        uint32_t tot = 0, c[CM2_WAVES];
-        const uint32_t d = threadIdx.x & (CM_RADIX - 1);
-        if (threadIdx.x < CM_RADIX) {
+        // thread t < 128: digits 2t and 2t+1 — totals over the waves, exclusive prefix over the digits, then every wave's
+        // counter becomes the first sorted position of its records of that digit
+        uint32_t cw[CM2_WAVES], t0 = 0, t1 = 0;
+        if (threadIdx.x < CM_RADIX / 2) {
 #pragma unroll
-            for (int q = 0; q < CM2_WAVES; ++q) { c[q] = whist[q][d]; tot += c[q]; }
+            for (int q = 0; q < CM2_WAVES; ++q) { cw[q] = whist[q][threadIdx.x]; t0 += cw[q] & 0xFFFFu; t1 += cw[q] >> 16; }
         }
         uint32_t tile_valid;
-        const uint32_t dbase = block_excl_scan_w<CM2_WAVES>(tot, lds, &tile_valid);
-        if (threadIdx.x < CM_RADIX) {
-            uint32_t run = dbase;
+        const uint32_t db = block_excl_scan_w<CM2_WAVES>(t0 + t1, lds, &tile_valid);
+        if (threadIdx.x < CM_RADIX / 2) {
+            uint32_t r0 = db, r1 = db + t0;
+            s_dbase[2 * threadIdx.x] = static_cast<uint16_t>(r0);
+            s_dbase[2 * threadIdx.x + 1] = static_cast<uint16_t>(r1);
 #pragma unroll
-            for (int q = 0; q < CM2_WAVES; ++q) { whist[q][d] = run; run += c[q]; }
-            gofs[d] = gbase + before - dbase;
-            if (d == 0) s_tile_valid = tile_valid;
+            for (int q = 0; q < CM2_WAVES; ++q) {
+                whist[q][threadIdx.x] = r0 | (r1 << 16);
+                r0 += cw[q] & 0xFFFFu; r1 += cw[q] >> 16;
+            }
+            if (threadIdx.x == 0) s_tile_valid = tile_valid;
         }
     }
     __syncthreads();
+    PH((FIRST ? 0 : 8) + 3);
+    if (threadIdx.x < CM_RADIX)                                  // (read again behind the barrier of the first staging round)
+        gofs[threadIdx.x] = gbase + before + gofs[threadIdx.x] - s_dbase[threadIdx.x];   // (+ the part threads 256-511 summed)
     const uint32_t tile_valid = s_tile_valid;
-    uint32_t lpos[CM2_ITEMS];
 #pragma unroll
     for (int r = 0; r < CM2_ITEMS; ++r) {
-        const uint32_t digit = (key[r] >> shift) & (CM_RADIX - 1);
-        lpos[r] = (vmask >> r & 1u) ? whist[w][digit] + rank[r] : 0xFFFFFFFFu;
+        const uint32_t digit = lp[r] & 0xFFu;
+        lp[r] = (vmask >> r & 1u) ? ((whist[w][digit >> 1] >> ((digit & 1u) * 16u)) & 0xFFFFu) + (lp[r] >> 16) : 0xFFFFFFFFu;
     }
     // Two rounds through the staging buffer: sorted positions [0, 2048), then [2048, 4096).
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const uint32_t lo = h * (CM_TILE / 2);
         if (h == 1) {
+            PH((FIRST ? 0 : 8) + 4);
             if (tile_valid <= lo) break;                   // uniform
             __syncthreads();
         }
 #pragma unroll
         for (int r = 0; r < CM2_ITEMS; ++r)
-            if (lpos[r] - lo < CM_TILE / 2) srec[lpos[r] - lo] = rec[r];
+            if (lp[r] - lo < CM_TILE / 2) srec[lp[r] - lo] = rec[r];
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < CM2_ITEMS / 2; ++j) {
@@ -458,6 +498,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 3) void k2_scatter(const CmFrameDev* __r
         }
     }
 
+    PH((FIRST ? 0 : 8) + 5);
     // The exact bounds of the cloud (pcl::getMinMax3D) for the result and for the next frame's box.
     if (FIRST && fold && tile == 0) {
         __syncthreads();
@@ -510,16 +551,6 @@ __global__ __launch_bounds__(CM2_BLOCK, 3) void k2_scatter(const CmFrameDev* __r
 #define CM2_FLAG_AGG (1ull << 32)
 #define CM2_FLAG_PREFIX (2ull << 32)
 
-// Phase timing of the local finish (scripts/phase_times.py; build with CM_PHASE_TIMING=1): thread 0 of every
-// workgroup stores the 100 MHz ticks between phase boundaries. Compiled out of the product build.
-#ifdef CM_PHASE_TIMING
-__device__ unsigned long long g_phase[4096 * 16];
-#define PH_START() long long t0_ = wall_clock64()
-#define PH(k) do { if (threadIdx.x == 0) { const long long t1_ = wall_clock64(); g_phase[(blockIdx.x & 4095) * 16 + (k)] = (unsigned long long)(t1_ - t0_); t0_ = t1_; } } while (0)
-#else
-#define PH_START() do {} while (0)
-#define PH(k) do {} while (0)
-#endif
 template <int LT, int LCAP, int LBLOCK, bool WRITEBACK>
 __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const CmFrameDev* __restrict__ fd,
                                                        CmFrameState* __restrict__ st,
@@ -896,17 +927,17 @@ extern "C" __attribute__((visibility("default"))) void cm_debug_phases(unsigned 
 }
 #endif
 
-void cmk2_hist0(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* hist, uint32_t* grp_acc,
+void cmk2_hist0(hipStream_t s, const CmFrameDev* fd, const CmTileDev* tiles, CmFrameState* st, uint32_t* hist, uint32_t* grp_acc,
                 uint32_t* grp_clear_a, uint32_t* grp_clear_b, uint32_t n_group_words, uint32_t n_clear_a_words,
                 unsigned long long* tile_state, uint32_t n_tile_state, float* records, int grid_mode, int check_box,
                 uint32_t shift0, uint32_t n_global_passes, uint32_t n_tiles, const unsigned char* mask,
                 const CmFrameState* st_outlier, int use_cell, void* compact_out, uint32_t* wave_cnt) {
     if (compact_out)
-        hipLaunchKernelGGL(k2_hist0<true>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, st, hist, grp_acc, grp_clear_a, grp_clear_b,
+        hipLaunchKernelGGL(k2_hist0<true>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, hist, grp_acc, grp_clear_a, grp_clear_b,
                            n_group_words, n_clear_a_words, tile_state, n_tile_state, records, grid_mode, check_box, shift0,
                            n_global_passes, mask, st_outlier, use_cell, reinterpret_cast<float4*>(compact_out), wave_cnt);
     else
-        hipLaunchKernelGGL(k2_hist0<false>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, st, hist, grp_acc, grp_clear_a, grp_clear_b,
+        hipLaunchKernelGGL(k2_hist0<false>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, hist, grp_acc, grp_clear_a, grp_clear_b,
                            n_group_words, n_clear_a_words, tile_state, n_tile_state, records, grid_mode, check_box, shift0,
                            n_global_passes, mask, st_outlier, use_cell, nullptr, nullptr);
 }
@@ -914,7 +945,7 @@ void cmk2_hist(hipStream_t s, const CmFrameState* st, const unsigned char* dig, 
                uint32_t n_tiles) {
     hipLaunchKernelGGL(k2_hist, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, st, dig, hist, grp);
 }
-void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, CmFrameState* st, const void* rec_in, void* rec_out,
+void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, const CmTileDev* tiles, CmFrameState* st, const void* rec_in, void* rec_out,
                   unsigned char* dig_out, const uint32_t* hist, const uint32_t* grp, const uint32_t* totals,
                   uint32_t shift, uint32_t next_shift, uint32_t n_tiles, uint32_t n_groups, uint32_t n_padded,
                   const float* records, uint32_t n_records, int fold, const unsigned char* mask, int use_cell,
@@ -922,11 +953,11 @@ void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, CmFrameState*
     const float4* in = reinterpret_cast<const float4*>(rec_in);
     float4* o = reinterpret_cast<float4*>(rec_out);
     if (first)
-        hipLaunchKernelGGL(k2_scatter<true>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, st, in, o, dig_out, hist, grp,
+        hipLaunchKernelGGL(k2_scatter<true>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, in, o, dig_out, hist, grp,
                            totals, shift, next_shift, n_groups, n_padded, records, n_records, fold, mask, use_cell,
                            reinterpret_cast<const float4*>(compact_in), wave_cnt);
     else
-        hipLaunchKernelGGL(k2_scatter<false>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, st, in, o, dig_out, hist, grp,
+        hipLaunchKernelGGL(k2_scatter<false>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, in, o, dig_out, hist, grp,
                            totals, shift, next_shift, n_groups, n_padded, records, n_records, fold, mask, use_cell,
                            reinterpret_cast<const float4*>(compact_in), wave_cnt);
 }

@@ -91,8 +91,8 @@ __device__ unsigned long long g_phase3[4096 * 16];
 // ------------------------------------------------------------------------------------------------
 // k3_local
 // ------------------------------------------------------------------------------------------------
-template <int LT, int LCAP, int LBLOCK, bool PARTIAL>
-__global__ __launch_bounds__(LBLOCK, 6) void k3_local(const CmFrameDev* __restrict__ fd,
+template <int LT, int LCAP, int LBLOCK, int WPS, bool PARTIAL>
+__global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __restrict__ fd,
                                                       CmFrameState* __restrict__ st,
                                                       uint32_t* __restrict__ host_state,
                                                       const float4* __restrict__ rec,
@@ -108,20 +108,23 @@ __global__ __launch_bounds__(LBLOCK, 6) void k3_local(const CmFrameDev* __restri
     __shared__ uint32_t sk[LCAP];                      // key of every slot
     __shared__ uint16_t si[LCAP];                      // slots in sorted order
     __shared__ uint32_t whist[LWAVES][HWORDS];         // digit counts per wave
-    __shared__ uint16_t dbase[BINS];                   // first sorted position of every digit
     __shared__ uint32_t lds[2 * LWAVES];
     __shared__ uint32_t s_a, s_keyprev, s_bad;
 
     PH3_START();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // (values that are the same in every lane are put into scalar registers by hand — the compiler cannot tell for what
+    // comes out of LDS or global memory — so that the loops below branch and count on the scalar unit)
+#define SCAL(x) static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(x)))
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = SCAL(threadIdx.x >> 6);
     if (st->status != CM_DEV_OK || st->outside) return;          // (k3_compact reports)
-    const uint32_t n = st->n_valid;
+    const uint32_t n = SCAL(st->n_valid);
     const uint32_t n_lt = (n + LT - 1) / LT;
     const uint32_t tile = blockIdx.x;
     if (tile >= n_lt) return;
     const BoxGrid3 b = box_grid3(fd);
     const uint32_t L = low_bits;
-    const uint32_t min_pts = (!PARTIAL && fd->min_pts > 1) ? fd->min_pts : 1u;
+    const uint32_t min_pts = SCAL((!PARTIAL && fd->min_pts > 1) ? fd->min_pts : 1u);
 
     // ---- load: the nominal tile, the key before it, and the first records after it
     const uint32_t base = tile * LT;
@@ -165,13 +168,13 @@ __global__ __launch_bounds__(LBLOCK, 6) void k3_local(const CmFrameDev* __restri
         }
         if (best != 0xFFFFFFFFu) atomicMin(&s_a, best);
     }
-    const uint32_t h_last = sk[nom - 1] >> L;
+    const uint32_t h_last = SCAL(sk[nom - 1] >> L);
     // ---- tail of the last bucket past the nominal end (a prefix of what follows: H is ascending)
     const bool in_e = threadIdx.x < EXT0 && nom == LT && (base + LT + threadIdx.x) < n;
     const bool m0 = in_e && (sk[LT + threadIdx.x] >> L) == h_last;
     bad_order = bad_order || (in_e && (sk[LT + threadIdx.x] >> L) < h_last);
-    uint32_t ext = __syncthreads_count(m0);               // also orders the atomicMin above
-    const uint32_t a = s_a;
+    uint32_t ext = SCAL(__syncthreads_count(m0));         // also orders the atomicMin above
+    const uint32_t a = SCAL(s_a);
     bool too_big = false;
     if (ext == EXT0 && a != 0xFFFFFFFFu) {
         for (uint32_t off = EXT0;; off += LBLOCK) {
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(LBLOCK, 6) void k3_local(const CmFrameDev* __restri
                 bad_order = bad_order || (k >> L) < h_last;
                 if (mm && pos < LCAP) sk[pos] = k;
             }
-            const uint32_t c = __syncthreads_count(mm);
+            const uint32_t c = SCAL(__syncthreads_count(mm));
             ext += c;
             if (LT + ext > LCAP) { too_big = true; break; }
             if (c < LBLOCK) break;
@@ -199,8 +202,9 @@ __global__ __launch_bounds__(LBLOCK, 6) void k3_local(const CmFrameDev* __restri
     // ---- sort the owned slots [a, a+m) by key: LSD over the bits in which the keys of this tile can differ, up to
     // 10 per pass, stable; only the slot numbers move. Ranking: returning LDS adds on per-wave counters.
     if (m) {
-        const uint32_t kbase = (sk[a] >> L) << L;
-        const unsigned long long span = static_cast<unsigned long long>(h_last - (sk[a] >> L) + 1u) << L;
+        const uint32_t h_first = SCAL(sk[a] >> L);
+        const uint32_t kbase = h_first << L;
+        const unsigned long long span = static_cast<unsigned long long>(h_last - h_first + 1u) << L;
         const uint32_t nb = span > 1ull ? 64u - static_cast<uint32_t>(__builtin_clzll(span - 1ull)) : 0u;
         const uint32_t npass = nb ? (nb + 9u) / 10u : 1u;
         const uint32_t width = nb ? (nb + npass - 1u) / npass : 0u;
@@ -215,7 +219,8 @@ __global__ __launch_bounds__(LBLOCK, 6) void k3_local(const CmFrameDev* __restri
             for (int r = 0; r < LITEMS; ++r) {
                 const uint32_t e = w * (64 * rounds) + r * 64 + lane;
                 ei[r] = 0; dg[r] = 0;
-                if (r < rounds && e < m) {
+                if (static_cast<uint32_t>(r) >= rounds) break;         // (uniform)
+                if (e < m) {
                     ei[r] = (p == 0) ? static_cast<uint16_t>(a + e) : si[e];
                     dg[r] = ((sk[ei[r]] - kbase) >> (p * width)) & dmask;
                 }
@@ -231,31 +236,44 @@ __global__ __launch_bounds__(LBLOCK, 6) void k3_local(const CmFrameDev* __restri
                 const uint32_t e = w * (64 * rounds) + r * 64 + lane;
                 const uint32_t sh = (dg[r] & 1u) * 16u;
                 rk[r] = 0;
-                if (r < rounds && e < m) rk[r] = (atomicAdd(&whist[w][dg[r] >> 1], 1u << sh) >> sh) & 0xFFFFu;
+                if (static_cast<uint32_t>(r) >= rounds) break;         // (uniform)
+                if (e < m) rk[r] = (atomicAdd(&whist[w][dg[r] >> 1], 1u << sh) >> sh) & 0xFFFFu;
             }
             __syncthreads();
-            // thread t < HWORDS: digits 2t and 2t+1 — exclusive prefix over the waves, then over the digits
-            uint32_t t0 = 0, t1 = 0;
+            // thread t < words: digits 2t and 2t+1. Totals over the waves, exclusive prefix over the digits (one barrier: the
+            // wave totals alternate between two sets of words from pass to pass), then every wave's counter becomes the
+            // first sorted position of its items of that digit — 16 bits each, positions stay below LCAP.
+            uint32_t cw[LWAVES], t0 = 0, t1 = 0;
             if (threadIdx.x < words) {
 #pragma unroll
-                for (int q = 0; q < LWAVES; ++q) {
-                    const uint32_t c = whist[q][threadIdx.x];
-                    whist[q][threadIdx.x] = t0 | (t1 << 16);
-                    t0 += c & 0xFFFFu; t1 += c >> 16;
-                }
+                for (int q = 0; q < LWAVES; ++q) { cw[q] = whist[q][threadIdx.x]; t0 += cw[q] & 0xFFFFu; t1 += cw[q] >> 16; }
             }
-            uint32_t all;
-            const uint32_t db = block_excl_scan3<LWAVES>(t0 + t1, lds, &all);
+            uint32_t db;
+            {
+                uint32_t* wl = lds + (p & 1u) * LWAVES;
+                const uint32_t incl = wave_incl_scan_u32(t0 + t1, lane);
+                if (lane == 63) wl[w] = incl;
+                __syncthreads();
+                uint32_t woff = 0;
+#pragma unroll
+                for (int q = 0; q < LWAVES; ++q) woff += (q < w) ? wl[q] : 0u;
+                db = woff + incl - (t0 + t1);
+            }
             if (threadIdx.x < words) {
-                dbase[2 * threadIdx.x] = static_cast<uint16_t>(db);
-                dbase[2 * threadIdx.x + 1] = static_cast<uint16_t>(db + t0);
+                uint32_t r0 = db, r1 = db + t0;
+#pragma unroll
+                for (int q = 0; q < LWAVES; ++q) {
+                    whist[q][threadIdx.x] = r0 | (r1 << 16);
+                    r0 += cw[q] & 0xFFFFu; r1 += cw[q] >> 16;
+                }
             }
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < LITEMS; ++r) {
                 const uint32_t e = w * (64 * rounds) + r * 64 + lane;
-                if (r < rounds && e < m) {
-                    const uint32_t pos = dbase[dg[r]] + ((whist[w][dg[r] >> 1] >> ((dg[r] & 1u) * 16u)) & 0xFFFFu) + rk[r];
+                if (static_cast<uint32_t>(r) >= rounds) break;         // (uniform)
+                if (e < m) {
+                    const uint32_t pos = ((whist[w][dg[r] >> 1] >> ((dg[r] & 1u) * 16u)) & 0xFFFFu) + rk[r];
                     si[pos] = ei[r];
                 }
             }
@@ -280,13 +298,16 @@ __global__ __launch_bounds__(LBLOCK, 6) void k3_local(const CmFrameDev* __restri
         uint32_t heads = 0, kheads = 0;
         const uint32_t kp = (i0 > 0 && i0 < m) ? sk[si[i0 - 1]] : 0u;
 #pragma unroll
+        for (int j = 0; j < LITEMS; ++j) { k[j] = 0; sl[j] = 0; }
+#pragma unroll
         for (int j = 0; j < LITEMS; ++j) {
-            k[j] = 0; sl[j] = 0;
-            if (static_cast<uint32_t>(j) < per && i0 + j < m) { sl[j] = si[i0 + j]; k[j] = sk[sl[j]]; }
+            if (static_cast<uint32_t>(j) >= per) break;        // (uniform)
+            if (i0 + j < m) { sl[j] = si[i0 + j]; k[j] = sk[sl[j]]; }
         }
 #pragma unroll
         for (int j = 0; j < LITEMS; ++j) {
-            if (static_cast<uint32_t>(j) < per && i0 + j < m) {
+            if (static_cast<uint32_t>(j) >= per) break;        // (uniform)
+            if (i0 + j < m) {
                 const uint32_t prev = j ? k[j ? j - 1 : 0] : kp;
                 if (i0 + j == 0 || k[j] != prev) {
                     heads |= 1u << j;
@@ -302,14 +323,17 @@ __global__ __launch_bounds__(LBLOCK, 6) void k3_local(const CmFrameDev* __restri
             bool on = false;
 #pragma unroll
             for (int j = 0; j < LITEMS; ++j) {
+                if (static_cast<uint32_t>(j) >= per) break;    // (uniform)
                 if ((heads >> j) & 1u) on = (kheads >> j) & 1u;
-                if (on && static_cast<uint32_t>(j) < per && i0 + j < m) ldm |= 1u << j;
+                if (on && i0 + j < m) ldm |= 1u << j;
             }
         }
         float4 r4[LITEMS];
 #pragma unroll
-        for (int j = 0; j < LITEMS; ++j)
+        for (int j = 0; j < LITEMS; ++j) {
+            if (static_cast<uint32_t>(j) >= per) break;        // (uniform)
             if ((ldm >> j) & 1u) r4[j] = rec[base + sl[j]];
+        }
         const uint32_t kid0 = block_excl_scan3<LWAVES>(static_cast<uint32_t>(__builtin_popcount(kheads)), lds, &c_t);
 
         auto emit = [&](uint32_t kid, uint32_t key, float sx, float sy, float sz, float sw, uint32_t cn) {
@@ -330,6 +354,7 @@ __global__ __launch_bounds__(LBLOCK, 6) void k3_local(const CmFrameDev* __restri
         bool on = false;
 #pragma unroll
         for (int j = 0; j < LITEMS; ++j) {
+            if (static_cast<uint32_t>(j) >= per) break;        // (uniform)
             if ((heads >> j) & 1u) {
                 if (on) emit(kid++, ckey, sx, sy, sz, sw, cn);
                 on = (kheads >> j) & 1u;
@@ -441,11 +466,11 @@ void cmk3_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t*
                 uint32_t n_padded) {
     const dim3 grid(n_padded / 2048);
     if (partial)
-        hipLaunchKernelGGL((k3_local<2048, 4096, 512, true>), grid, dim3(512), 0, s, fd, st, host_state,
+        hipLaunchKernelGGL((k3_local<2048, 3968, 512, 8, true>), grid, dim3(512), 0, s, fd, st, host_state,
                            reinterpret_cast<const float4*>(rec), reinterpret_cast<uint2*>(tile_info), grp_cnt,
                            reinterpret_cast<float4*>(stage), nullptr, nullptr, low_bits);
     else
-        hipLaunchKernelGGL((k3_local<2048, 4096, 512, false>), grid, dim3(512), 0, s, fd, st, host_state,
+        hipLaunchKernelGGL((k3_local<2048, 3968, 512, 8, false>), grid, dim3(512), 0, s, fd, st, host_state,
                            reinterpret_cast<const float4*>(rec), reinterpret_cast<uint2*>(tile_info), grp_cnt,
                            reinterpret_cast<float4*>(stage), stage_key, stage_cnt, low_bits);
 }
