@@ -306,7 +306,9 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __r
                                                            uint32_t n_records, int fold,
                                                            const unsigned char* __restrict__ mask, int use_cell,
                                                            const float4* __restrict__ compact_in,
-                                                           const uint32_t* __restrict__ wave_cnt) {
+                                                           const uint32_t* __restrict__ wave_cnt, int debug_swap) {
+    // debug_swap (tests only, CM_DEBUG_MISRANK=1): the first and the last record of tile 0's sorted tile change places on
+    // their way out — what a mis-ranked pass would look like to the finish, which must notice (CM_DEV_ERR_UNSORTED).
     // 37 KB of LDS and at most 64 VGPRs: four workgroups per CU, so that the 977 tiles of a 4 M-point frame are all
     // resident at once (with three per CU the last 209 tiles ran as a second, nearly empty generation)
     __shared__ float4 srec[CM_TILE / 2];                // staging in two halves
@@ -491,7 +493,14 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __r
             if (t < tile_valid) {
                 const float4 r4 = srec[t - lo];
                 const uint32_t k = key_of(b, r4);
-                const uint32_t pos = gofs[(k >> shift) & (CM_RADIX - 1)] + t;
+                uint32_t pos = gofs[(k >> shift) & (CM_RADIX - 1)] + t;
+                if (debug_swap && tile == 0 && h == 0 && tile_valid > 1) {
+                    const uint32_t last = min(tile_valid, static_cast<uint32_t>(CM_TILE / 2)) - 1u;   // (both in the first staging round)
+                    if (t == 0 || t == last) {
+                        const uint32_t to = t == 0 ? last : 0u;
+                        pos = gofs[(key_of(b, srec[to]) >> shift) & (CM_RADIX - 1)] + to;
+                    }
+                }
                 rec_out[pos] = r4;
                 if (next_shift < 32u) dig_out[pos] = static_cast<unsigned char>((k >> next_shift) & 0xFFu);
             }
@@ -637,7 +646,9 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
     __syncthreads();
     PH(1);
 
-    // ---- a: first bucket start in the nominal tile
+    // ---- a: first bucket start in the nominal tile; the bucket number must not decrease anywhere (free check of the
+    // global passes' ranking, as k3_local does: CM_DEV_ERR_UNSORTED hands the frame back)
+    bool bad_order = false;
     {
         uint32_t best = 0xFFFFFFFFu;
 #pragma unroll
@@ -646,9 +657,14 @@ __global__ __launch_bounds__(LBLOCK, LBLOCK <= 512 ? 6 : 4) void k2_local(const 
             if (q < nom) {
                 const uint32_t kp = (q == 0) ? s_keyprev : sk[q - 1];
                 if ((base + q == 0) || ((sk[q] >> L) != (kp >> L))) best = q;
+                bad_order = bad_order || (base + q > 0 && (sk[q] >> L) < (kp >> L));
             }
         }
         if (best != 0xFFFFFFFFu) atomicMin(&s_a, best);
+    }
+    if (bad_order) {
+        host_state[offsetof(CmFrameState, err) / 4] = CM_DEV_ERR_UNSORTED;
+        if (WRITEBACK) st->status = CM_DEV_ABORTED;          // (nobody may index with what this stage leaves behind)
     }
     const uint32_t h_last = sk[nom - 1] >> L;
     // ---- tail of the last bucket past the nominal end (a prefix of what follows: H is ascending)
@@ -949,17 +965,17 @@ void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, const CmTileD
                   unsigned char* dig_out, const uint32_t* hist, const uint32_t* grp, const uint32_t* totals,
                   uint32_t shift, uint32_t next_shift, uint32_t n_tiles, uint32_t n_groups, uint32_t n_padded,
                   const float* records, uint32_t n_records, int fold, const unsigned char* mask, int use_cell,
-                  const void* compact_in, const uint32_t* wave_cnt) {
+                  const void* compact_in, const uint32_t* wave_cnt, int debug_swap) {
     const float4* in = reinterpret_cast<const float4*>(rec_in);
     float4* o = reinterpret_cast<float4*>(rec_out);
     if (first)
         hipLaunchKernelGGL(k2_scatter<true>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, in, o, dig_out, hist, grp,
                            totals, shift, next_shift, n_groups, n_padded, records, n_records, fold, mask, use_cell,
-                           reinterpret_cast<const float4*>(compact_in), wave_cnt);
+                           reinterpret_cast<const float4*>(compact_in), wave_cnt, debug_swap);
     else
         hipLaunchKernelGGL(k2_scatter<false>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, in, o, dig_out, hist, grp,
                            totals, shift, next_shift, n_groups, n_padded, records, n_records, fold, mask, use_cell,
-                           reinterpret_cast<const float4*>(compact_in), wave_cnt);
+                           reinterpret_cast<const float4*>(compact_in), wave_cnt, debug_swap);
 }
 void cmk2_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next, uint32_t* host_state,
                 const void* rec, unsigned long long* tile_state, uint32_t* ticket, void* out, uint32_t* out_key,

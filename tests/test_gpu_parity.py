@@ -24,7 +24,7 @@ def sort_path(request, monkeypatch):
     return request.param
 
 
-BUCKET, PREDICTED, REDONE, PACKED = 2, 4, 8, 16          # cm_result.path_flags (CM_PATH_*)
+BUCKET, PREDICTED, REDONE, PACKED, SPLIT = 2, 4, 8, 16, 32   # cm_result.path_flags (CM_PATH_*)
 
 STATUS = {"OK": capi.OK, "EMPTY_INPUT": capi.EMPTY_INPUT, "GRID_OVERFLOW": capi.GRID_OVERFLOW}
 
@@ -726,3 +726,52 @@ def test_bucket_path_one_to_three_global_passes(leaf, half, n_pass, sort_path):
     assert g["res"].bounds_from_crop == 1
     if sort_path == "auto" and g["res"].path_flags & 1:
         assert g["res"].path_flags & BUCKET and g["res"].sort_passes == n_pass
+
+
+def test_mis_ranked_global_pass_is_noticed_and_redone(sort_path, monkeypatch):
+    """the bucket path relies on lane-ordered returning LDS adds for its stable ranking (probed once
+    at cm_create). The finish checks what the global passes hand it — the bucket number must not decrease from one
+    record to the next. CM_DEBUG_MISRANK=1 (test hook) makes the last global pass swap two records of tile 0 on their
+    way out: the frame must come back CM_PATH_REDONE with the oracle's result, and the context stops trusting the
+    LDS ranking (no bucket path afterwards, ballot ranking on the general path)."""
+    sensors, params = synth.config2(n_per_sensor=30_000, min_pts=0)
+    params.crop_min, params.crop_max = (-60.0,) * 3, (60.0,) * 3          # a box from the first frame on
+    st, _, out, rep = oracle.merge_voxelize(sensors, params, threads=4, stable=True)
+    with capi.CloudMerger(max_points_total=120_000, max_sensors=4, flags=capi.FLAG_OCCUPANCY) as cm:
+        bucket_here = bool(run_gpu(sensors, params, want_merged=False, cm=cm)["res"].path_flags & BUCKET)   # without the hook
+    monkeypatch.setenv("CM_DEBUG_MISRANK", "1")
+    with capi.CloudMerger(max_points_total=120_000, max_sensors=4, flags=capi.FLAG_OCCUPANCY) as cm:
+        flags = []
+        for _ in range(2):
+            g = run_gpu(sensors, params, want_merged=False, cm=cm)
+            assert g["res"].status == st == capi.OK and g["res"].n_out == rep.n_out
+            assert np.array_equal(g["cells"], rep.cells) and np.array_equal(g["counts"], rep.counts)
+            assert_centroids_close(g["out"], xyzi_of(out))
+            flags.append(g["res"].path_flags)
+    if not bucket_here:
+        assert not any(f & (BUCKET | REDONE) for f in flags)       # (general path: the hook has nothing to touch)
+    else:
+        assert flags[0] & REDONE and not flags[0] & 1, "handed back, LDS ranking dropped"
+        assert not flags[1] & (BUCKET | REDONE | 1), "the bucket path stays off on this context"
+
+
+@pytest.mark.parametrize("min_pts", [0, 2, 3])
+def test_both_finish_kernels_agree_with_the_oracle(min_pts, sort_path, monkeypatch):
+    """The bucket path's finish exists twice: k3_local + k3_compact (default, CM_PATH_SPLIT) and k2_local with its
+    look-back (CM_FINISH=v2; still what the outlier stage's sort builds on). Same frame, both against the oracle."""
+    if sort_path == "classic":
+        pytest.skip("bucket path only")
+    sensors, params = synth.config2(n_per_sensor=150_000, min_pts=min_pts)
+    seen = []
+    for finish in ("", "v2"):
+        monkeypatch.setenv("CM_FINISH", finish)
+        with capi.CloudMerger(max_points_total=600_000, max_sensors=4, flags=capi.FLAG_OCCUPANCY) as cm:
+            for frame in range(2):                     # the second frame runs in the predicted box
+                g = run_gpu(sensors, params, want_merged=False, cm=cm)
+        st, _, out, rep = oracle.merge_voxelize(sensors, params, threads=4, stable=True)
+        assert g["res"].status == st == capi.OK and g["res"].n_out == rep.n_out
+        assert np.array_equal(g["cells"], rep.cells) and np.array_equal(g["counts"], rep.counts)
+        if g["res"].path_flags & BUCKET:
+            assert same_bits(g["out"], xyzi_of(out))
+            seen.append(bool(g["res"].path_flags & SPLIT))
+    assert seen in ([], [True, False])
