@@ -34,7 +34,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3])
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
+                    help="2: headline (BASELINE.json configs[1]); 3: configs[2]; 5: configs[4], the single fused cloud — the "
+                         "16 sensors dealt to the ranks, partial tables all-gathered (RCCL), merged on every rank")
+    ap.add_argument("--points-per-sensor", type=int, default=0, help="config 5 only: points per sensor (default 4 M)")
+    ap.add_argument("--check", action="store_true", help="config 5 only: compare the fused cloud with the CPU oracle on rank 0 "
+                                                          "(builds all 16 sensors there: reduced sizes only)")
     ap.add_argument("--min-pts", type=int, default=2, help="min points per voxel (reference: 2, PCL default: 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -50,8 +55,134 @@ def parse():
     return ap.parse_args()
 
 
+def main_fused(args):
+    """BASELINE.json configs[4]: 16 sensors x 4 M points, 1 cm voxel, crop x[-15,45] y[-5,5] z[-0.5,3]; ONE fused cloud.
+    Rank r (one process per GPU) holds the sensors s = r mod world. A step = one frame: cm_merge_partial on the rank's
+    sensors (bucket path -> per-voxel sums, threshold deferred), all-gather of the tables (lengths first) over
+    torch.distributed — "nccl" = RCCL over xGMI; "gloo" + --single-device rehearses the same code on one GPU with the
+    exchange on the host — and cm_merge_tables on every rank (every rank ends up with the whole fused cloud, as an
+    all-gather implies). Reference: fusePointclouds + voxelgrid, pc_preprocessing_main.cpp:131-177."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    host_x = args.backend == "gloo"
+    if world > 1:
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    from cloud_merger_amd import capi, fused, synth
+    n_sensors = 16
+    nps = args.points_per_sensor or 4_000_000
+    sensors, params = synth.config5_shard(rank, world, n_per_sensor=nps, n_sensors=n_sensors, min_pts=args.min_pts)
+    n_rank = sum(s.n for s in sensors)
+    n_total = n_sensors * nps
+    dev_clouds = [torch.from_numpy(np.ascontiguousarray(s.data).view(np.uint8).reshape(-1)).to(dev) for s in sensors]
+    torch.cuda.synchronize()
+    cm = capi.CloudMerger(max_points_total=max(n_rank, 1 << 16), max_sensors=max(1, len(sensors)), device=local_rank,
+                          flags=capi.FLAG_OCCUPANCY if args.check else 0)
+    cm.set_stream(torch.cuda.current_stream().cuda_stream)
+    for k, s in enumerate(sensors):
+        cm.set_transform(k, s.q_xyzw, s.t_xyz)
+
+    acc = {"partial_ms": 0.0, "exchange_ms": 0.0, "merge_ms": 0.0}
+    last = {}
+
+    def step():
+        for k, s in enumerate(sensors):
+            cm.submit_device(k, dev_clouds[k].data_ptr(), s.n, s.point_step, s.off_x, s.off_y, s.off_z, s.off_i)
+        t = {}
+        res = fused.fused_cloud(cm, params, dist if world > 1 else None, rank, world, dev, host_exchange=host_x, times=t)
+        for k in acc:
+            acc[k] += t[k]
+        last.update(t)
+        return res
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        res = step()
+    for k in acc:
+        acc[k] = 0.0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if res.status != capi.OK:
+        raise SystemExit(f"fused cloud status {capi.status_string(res.status)}")
+    if world > 1:
+        tmax = torch.tensor([elapsed] + [acc[k] for k in ("partial_ms", "exchange_ms", "merge_ms")], dtype=torch.float64,
+                            device="cpu" if host_x else dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax[0].item())
+        worst = {k: float(tmax[1 + i].item()) / args.steps for i, k in enumerate(("partial_ms", "exchange_ms", "merge_ms"))}
+    else:
+        worst = {k: acc[k] / args.steps for k in acc}
+    n_out = int(res.n_out)
+    ms = 1e3 * elapsed / args.steps
+    # per GPU: the rank reads its own points once and writes the whole fused cloud once (SURVEY.md 8d's accounting
+    # applied to what one GPU does); the exchange is reported beside it, in ms and in table bytes
+    b_alg_gpu = 16.0 * n_rank + 16.0 * n_out
+    out = {
+        "metric": "fused-cloud merged+voxelized points/sec at 1 cm leaf, 16x4 M-pt inputs; HBM GB/s fraction per GPU",
+        "value": args.steps * n_total / elapsed, "unit": "points/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"cfg5: {n_sensors} x {nps} XYZI float32 points, yaw-only SE(3), 1 cm voxel, crop x[-15,45] y[-5,5] "
+                               "z[-0.5,3]; one fused cloud on every rank",
+                   "points_per_frame": n_total, "points_per_rank": n_rank, "voxels_out": n_out,
+                   "min_points_per_voxel": args.min_pts, "sharding": f"sensor s on rank s mod {world}",
+                   "collective": ("all-gather of partial voxel tables (lengths, then padded tables) over torch.distributed "
+                                  + ("nccl = RCCL" if args.backend == "nccl" else "gloo on host copies (rehearsal)")) if world > 1
+                                 else "none (one rank)",
+                   "step_ms_worst_rank": worst,
+                   "table_entries_this_rank": int(last.get("table_entries", 0)),
+                   "gathered_entries": int(last.get("gathered_entries", 0)),
+                   "gathered_bytes": 32 * int(last.get("gathered_entries", 0)),
+                   "rehearsal_single_device": bool(args.single_device)},
+        "roofline": {"bound": "hbm", "achieved": b_alg_gpu / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": b_alg_gpu / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "scope": "per GPU: (16 B x this rank's input points + 16 B x fused voxels) / step time"},
+    }
+    if args.check and rank == 0:
+        from oracle import oracle
+        allsens = synth.config5_shard(0, 1, n_per_sensor=nps, n_sensors=n_sensors, min_pts=args.min_pts)[0]   # all 16, in sensor order
+        st, _, ref, rep = oracle.merge_voxelize(allsens, params, threads=6, stable=True, want_merged=False)
+        cells, counts = cm.cells(n_out)
+        got = cm.result(n_out)
+        ok = st == oracle.OK and rep.n_out == n_out and np.array_equal(rep.cells, cells) and np.array_equal(rep.counts, counts)
+        dx = float(max(np.abs(got[a].astype(np.float64) - ref[a].astype(np.float64)).max() for a in ("x", "y", "z"))) if ok and n_out else None
+        out["parity"] = {"occupancy_bit_exact": bool(ok), "max_abs_dxyz_m": dx}
+        if not ok or (dx is not None and dx > 1e-4):
+            print(json.dumps(out))
+            raise SystemExit("fused cloud differs from the oracle")
+    if rank == 0:
+        print(json.dumps(out))
+    cm.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.config == 5:
+        return main_fused(args)
     import numpy as np
     import torch
     import torch.distributed as dist

@@ -82,24 +82,62 @@ def merge_tables_numpy(tables, min_pts):
     return cat["key"][head][keep], cnt[keep], cent
 
 
-def fused_cloud(cm, params, dist, rank, world, device):
+def fused_cloud(cm, params, dist, rank, world, device, host_exchange=False, times=None):
     """Whole exchange on one rank whose sensors are already submitted to `cm` (a capi.CloudMerger on
-    `device`). Returns the cm_result of the merged cloud; read it with cm.result()/cm.cells()."""
+    `device`). Returns the cm_result of the merged cloud; read it with cm.result()/cm.cells().
+
+    host_exchange: the collectives run on CPU tensors (the gloo rehearsal: several ranks on one GPU); the
+    tables go device -> host -> all-gather -> device. With "nccl" (= RCCL) they stay in HBM and travel over xGMI.
+    times: optional dict that receives the wall time of the three steps in ms (partial, exchange, merge).
+    A rank whose cm_merge_partial fails (its sensors not fresh, a bad argument ...) must not leave the others
+    hanging in the all-gather: the ranks all-reduce a status word first and every rank raises together."""
+    import time
     import torch
-    bounds = None
-    if params.crop_min is None:
-        mn, mx, n_valid = cm.local_bounds(params)
-        bounds = allreduce_bounds(dist, mn, mx, n_valid, device=device) if world > 1 else \
-            (np.concatenate([mn, mx]) if n_valid else None)
-    part = cm.merge_partial(params, bounds)
+    from .capi import CloudMergeError
+    xdev = torch.device("cpu") if host_exchange else device
+    t0 = time.perf_counter()
+    bounds, err = None, None
+    try:
+        if params.crop_min is None:
+            mn, mx, n_valid = cm.local_bounds(params)
+            bounds = allreduce_bounds(dist, mn, mx, n_valid, device=xdev) if world > 1 else \
+                (np.concatenate([mn, mx]) if n_valid else None)
+        part = cm.merge_partial(params, bounds)
+        status = int(part.status)
+    except CloudMergeError as e:               # (a rank-local failure: report it to everybody below)
+        err, status, part = e, int(e.status), None
+    bad = status not in (0, 1)                 # OK or EMPTY_INPUT (an empty share is a valid share)
+    if world > 1:
+        flag = torch.tensor([1 if bad else 0], dtype=torch.int32, device=xdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        any_bad = bool(flag.item())
+    else:
+        any_bad = bad
+    if any_bad:
+        raise err if err is not None else CloudMergeError(status if bad else -5, "fused_cloud: another rank's partial table failed")
     n = int(part.n_out) if part.status == 0 else 0
-    table = torch.zeros((max(n, 1), ENTRY_WORDS), dtype=torch.int32, device=device)
+    # (torch.empty, and nothing of torch's pending on the buffer: the library copies on ITS stream, which need not be
+    # torch's — a zero-fill still queued on torch's stream would race with that copy)
+    table = torch.empty((max(n, 1), ENTRY_WORDS), dtype=torch.int32, device=device)
+    torch.cuda.synchronize(device)
     if n:
         cm.partial_to_device(table.data_ptr(), n)
+    else:
+        table.zero_()
+    torch.cuda.synchronize(device)
+    t1 = time.perf_counter()
     if world > 1:
-        gathered, counts = allgather_tables(dist, table, n, world)
+        gathered, counts = allgather_tables(dist, table.to(xdev) if host_exchange else table, n, world)
+        if host_exchange:
+            gathered = gathered.to(device)
     else:
         gathered, counts = table.unsqueeze(0), [n]
     torch.cuda.synchronize(device)
+    t2 = time.perf_counter()
     ptrs = [gathered[r].data_ptr() for r in range(world)]
-    return cm.merge_tables(ptrs, counts, params)
+    res = cm.merge_tables(ptrs, counts, params)
+    t3 = time.perf_counter()
+    if times is not None:
+        times.update(partial_ms=1e3 * (t1 - t0), exchange_ms=1e3 * (t2 - t1), merge_ms=1e3 * (t3 - t2),
+                     table_entries=n, gathered_entries=int(sum(counts)))
+    return res

@@ -152,6 +152,55 @@ def test_two_rank_fused_cloud_on_one_gpu(crop, path, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("min_pts", [0, 2])
+def test_cfg5_shape_contexts_as_ranks(world, min_pts):
+    """BASELINE.json configs[4] at reduced size: 16 sensors, 1 cm voxels, crop x[-15,45] y[-5,5] z[-0.5,3] (a 31-bit
+    index: 6001 x 1001 x 351 cells), the sensors dealt to 2 or 4 ranks (contexts on one GPU), cm_merge_partial ->
+    tables -> cm_merge_tables against the oracle on all 16 sensors. The points are drawn denser than cfg5's (a 12 m
+    scene) so that voxels are shared between ranks and the deferred threshold matters."""
+    from cloud_merger_amd import capi
+    from cloud_merger_amd.types import SensorCloud
+    n_sensors, nps = 16, 30_000
+    per_rank = [synth.config5_shard(r, world, n_per_sensor=nps, n_sensors=n_sensors, min_pts=min_pts) for r in range(world)]
+    params = per_rank[0][1]
+    # squeeze every cloud into a 12 m x 4 m patch in front of the vehicle so that the 1 cm voxels collide
+    for sens, _ in per_rank:
+        for s in sens:
+            s.data["x"] = s.data["x"] * np.float32(0.15); s.data["y"] = s.data["y"] * np.float32(0.05)
+            s.data["z"] = np.round(s.data["z"] * np.float32(20)) / np.float32(20)
+            s.data["x"] = np.round(s.data["x"] * np.float32(20)) / np.float32(20)
+    allsens = [None] * n_sensors
+    for r in range(world):
+        for k, s in enumerate(fused.shard_sensors(n_sensors, r, world)):
+            allsens[s] = per_rank[r][0][k]
+    cms, parts = [], []
+    try:
+        for r in range(world):
+            cm = capi.CloudMerger(max_points_total=n_sensors * nps, max_sensors=n_sensors, flags=capi.FLAG_OCCUPANCY)
+            for k, sc in enumerate(per_rank[r][0]):
+                cm.set_transform(k, sc.q_xyzw, sc.t_xyz)
+                cm.submit(k, sc)
+            cms.append(cm)
+            res = cm.merge_partial(params, None)
+            assert res.status == capi.OK and res.key_bits == 31
+            parts.append(cm.partial_device())
+        shared = sum(p[1] for p in parts)
+        res = cms[world - 1].merge_tables([p[0] for p in parts], [p[1] for p in parts], params)
+        out = cms[world - 1].result(res.n_out)
+        cells, counts = cms[world - 1].cells(res.n_out)
+        st, _, ref, rep = oracle.merge_voxelize(allsens, params, threads=4, stable=True)
+        assert res.status == st == capi.OK and res.n_out == rep.n_out > 0
+        assert shared > res.n_merged, "the case must have voxels that live on several ranks"
+        assert np.array_equal(cells, rep.cells) and np.array_equal(counts, rep.counts)
+        got = np.stack([out["x"], out["y"], out["z"], out["intensity"]], axis=1)
+        assert_centroids_close(got, xyzi_of(ref))
+    finally:
+        for cm in cms:
+            cm.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("crop", [True, False])
 def test_rank_with_an_empty_share_still_merges_on_the_shared_grid(crop):
     """Rank 0's only sensor delivered an empty cloud: its partial table is empty, but cm_merge_tables on it must
@@ -220,3 +269,28 @@ def test_fused_cloud_world1_equals_plain_path():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _WORLD1_SCRIPT, root], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_cfg5_runner_two_processes_gloo_on_one_gpu():
+    """`bench.py --config 5` as the driver would launch it, rehearsed on one GPU: two ranks (processes) under
+    torch.distributed.run, --backend gloo --single-device, reduced size, --check: every rank runs cm_merge_partial on
+    its 8 sensors, the REAL tables are all-gathered (on host copies here; RCCL on a node) and merged with
+    cm_merge_tables; rank 0 compares the fused cloud with the oracle on all 16 sensors and exits non-zero on a
+    difference."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("CM_PATH", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--config", "5", "--backend", "gloo",
+           "--single-device", "--points-per-sensor", "150000", "--steps", "3", "--warmup", "1", "--check", "--min-pts", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["points_per_frame"] == 16 * 150000
+    assert out["parity"]["occupancy_bit_exact"] and out["parity"]["max_abs_dxyz_m"] <= 1e-4
+    assert out["config"]["gathered_entries"] >= out["config"]["voxels_out"] > 0
