@@ -33,6 +33,7 @@ SYMBOLS = [
     "cm_last_error", "cm_version", "cm_host_alloc", "cm_host_free",
     "cm_local_bounds", "cm_merge_partial", "cm_partial_device", "cm_partial_copy", "cm_merge_tables",
     "cm_set_ground_removal", "cm_ground_copy", "cm_ground_planes",
+    "cm_submit_cloud_async", "cm_result_copy_async", "cm_sync", "cm_get_frame_stats",
 ]
 MAX_ZONES = 8
 
@@ -94,6 +95,13 @@ def make_ground_params(zones_per_sensor, max_iterations=1000, distance_threshold
     return g
 
 
+class FrameStats(C.Structure):
+    _fields_ = [("n_sensors", C.c_uint32), ("_pad", C.c_uint32), ("sensor", C.c_uint32 * MAX_SENSORS),
+                ("n_in", C.c_uint32 * MAX_SENSORS), ("n_kept", C.c_uint32 * MAX_SENSORS), ("fresh", C.c_uint32 * MAX_SENSORS),
+                ("generation", C.c_uint64 * MAX_SENSORS), ("bytes_h2d", C.c_uint64 * MAX_SENSORS), ("bytes_h2d_total", C.c_uint64), ("bytes_d2h_total", C.c_uint64),
+                ("bytes_algorithmic", C.c_uint64)]
+
+
 class StageTimes(C.Structure):
     _fields_ = [("n_stages", C.c_uint32), ("_pad", C.c_uint32),
                 ("name", (C.c_char * 24) * MAX_STAGES), ("ms", C.c_float * MAX_STAGES)]
@@ -130,6 +138,10 @@ def load():
     L.cm_get_sensor_matrix.argtypes = [vp, u32, C.POINTER(C.c_float)]
     L.cm_submit_cloud.argtypes = [vp, u32, vp, u32, u32, u32, u32, u32, u32]
     L.cm_submit_cloud_device.argtypes = [vp, u32, vp, u32, u32, u32, u32, u32, u32]
+    L.cm_submit_cloud_async.argtypes = [vp, u32, vp, u32, u32, u32, u32, u32, u32]
+    L.cm_result_copy_async.argtypes = [vp, vp, u64]
+    L.cm_sync.argtypes = [vp]
+    L.cm_get_frame_stats.argtypes = [vp, C.POINTER(FrameStats)]
     L.cm_clear_sensor.argtypes = [vp, u32]
     L.cm_merge_voxelize.argtypes = [vp, C.POINTER(Params), C.POINTER(Result)]
     L.cm_merge_voxelize_async.argtypes = [vp, C.POINTER(Params)]
@@ -263,6 +275,29 @@ class CloudMerger:
         return self._check(self._lib.cm_submit_cloud(self._ctx, sensor, data.ctypes.data, cloud.n, cloud.point_step,
                                                      cloud.off_x, cloud.off_y, cloud.off_z, off_i), "cm_submit_cloud",
                            ok=(OK, SKIPPED))
+
+    def submit_async(self, sensor, cloud: SensorCloud, host_ptr=None):
+        """cm_submit_cloud_async: the payload (cloud.data, or host_ptr: e.g. pinned memory) must stay alive and unchanged
+        until the frame that consumes it has been waited for."""
+        ptr = host_ptr if host_ptr is not None else np.ascontiguousarray(cloud.data).ctypes.data
+        off_i = NO_FIELD if cloud.off_i is None else cloud.off_i
+        return self._check(self._lib.cm_submit_cloud_async(self._ctx, sensor, C.c_void_p(ptr), cloud.n, cloud.point_step,
+                                                           cloud.off_x, cloud.off_y, cloud.off_z, off_i), "cm_submit_cloud_async",
+                           ok=(OK, SKIPPED))
+
+    def result_async(self, host_ptr, capacity):
+        self._check(self._lib.cm_result_copy_async(self._ctx, C.c_void_p(host_ptr), int(capacity)), "cm_result_copy_async")
+
+    def sync(self):
+        self._check(self._lib.cm_sync(self._ctx), "cm_sync")
+
+    def frame_stats(self):
+        fs = FrameStats()
+        self._check(self._lib.cm_get_frame_stats(self._ctx, C.byref(fs)), "cm_get_frame_stats")
+        k = fs.n_sensors
+        return {"sensor": list(fs.sensor[:k]), "n_in": list(fs.n_in[:k]), "n_kept": list(fs.n_kept[:k]), "fresh": list(fs.fresh[:k]),
+                "generation": list(fs.generation[:k]), "bytes_h2d": list(fs.bytes_h2d[:k]), "bytes_h2d_total": fs.bytes_h2d_total, "bytes_d2h_total": fs.bytes_d2h_total,
+                "bytes_algorithmic": fs.bytes_algorithmic}
 
     def submit_device(self, sensor, dev_ptr, n, point_step=16, off_x=0, off_y=4, off_z=8, off_i=12):
         off_i = NO_FIELD if off_i is None else off_i

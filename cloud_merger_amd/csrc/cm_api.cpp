@@ -31,15 +31,32 @@
 
 namespace {
 
+// A cloud as a frame sees it: where its payload lies in HBM and how its points are laid out.
+struct SlotCloud {
+    const void* dptr = nullptr;      // an owned buffer of the slot or a caller-owned device pointer
+    uint32_t n = 0, step = 0, ox = 0, oy = 0, oz = 0, oi = 0;
+};
+
+// One sensor. Two owned HBM buffers: the frame that was enqueued last reads `active` (and so do its by-products:
+// cm_merged_copy, cm_ground_copy, the overflow fallback, a hand-back's redo) until the NEXT frame is enqueued;
+// a submit meanwhile always goes to the other buffer and becomes `staged`. Nothing a subscriber thread does can
+// therefore touch what a frame in flight — or its by-products afterwards — read, and cm_submit_cloud never waits for a
+// merge (the reference's callbacks run beside its 10 Hz loop: pc_preprocessing_main.cpp:513, :318-337, :549-584).
 struct Slot {
     std::mutex mu;
-    void* dbuf = nullptr;            // owned HBM buffer (host submits)
-    size_t dcap = 0;
-    const void* dptr = nullptr;      // active payload: dbuf or a caller-owned device pointer
-    uint32_t n = 0, step = 0, ox = 0, oy = 0, oz = 0, oi = 0;
-    bool has_data = false, fresh = false;
+    void* buf[2] = {nullptr, nullptr};   // owned HBM buffers (host submits)
+    size_t cap[2] = {0, 0};
+    int active_buf = -1;                 // which of them `active` lives in (-1: none / a caller-owned pointer)
+    SlotCloud active, staged;
+    bool has_data = false;               // `active` (or, while fresh, `staged`) holds a cloud
+    bool fresh = false;                  // `staged` holds a cloud no frame has consumed yet
+    bool copy_pending = false;           // its H2D copy was enqueued without waiting (cm_submit_cloud_async): ev_copy tells
     float m[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copy = nullptr;
+    uint64_t bytes_h2d = 0;              // payload bytes of the staged cloud that crossed PCIe (0: device submit)
+    uint64_t active_bytes_h2d = 0;
+    uint64_t gen = 0, active_gen = 0;    // accepted submits so far; the one `active` came from
 };
 
 }  // namespace
@@ -143,6 +160,14 @@ struct cm_ctx {
     int cell_min_b[3] = {0, 0, 0}, cell_div_b[3] = {1, 1, 1};   // grid the cells in out_key are relative to
     uint64_t n_redone = 0;               // frames the bucket path handed back to the classic one
 
+    // per-sensor figures of the last enqueued frame (cm_frame_stats)
+    uint32_t stats_n_sensors = 0;
+    uint32_t stats_sensor[CM_MAX_SENSORS] = {0}, stats_n[CM_MAX_SENSORS] = {0}, stats_fresh[CM_MAX_SENSORS] = {0};
+    uint64_t stats_bytes[CM_MAX_SENSORS] = {0}, stats_gen[CM_MAX_SENSORS] = {0};
+    uint32_t* d_tile_kept = nullptr;     // per 4096-slot tile: points that passed crop / masks and entered the sort — the first scatter
+    uint32_t* h_tile_kept = nullptr;     // writes them straight into pinned host memory (d_tile_kept is its device view)
+    uint64_t bytes_d2h = 0;              // result / merged / ground bytes copied to the host since the frame was enqueued
+
     std::vector<hipEvent_t> prof_ev;
     std::vector<std::string> prof_names;
     size_t prof_used = 0;
@@ -242,9 +267,11 @@ void free_all(cm_ctx* c) {
     F(c->d_ground); F(c->d_state_g); F(c->gmask); F(c->zone_off); F(c->d_planes); F(c->hyp0); F(c->valid0); F(c->counts0); F(c->chunk_sums); F(c->bmask); F(c->zcode);
     F(c->d_frame); F(c->d_tiles); F(c->d_state[0]); F(c->d_state[1]);
     if (c->h_state) (void)hipHostFree(c->h_state);
+    if (c->h_tile_kept) (void)hipHostFree(c->h_tile_kept);
     for (auto& s : c->slots) {
-        F(s.dbuf);
+        F(s.buf[0]); F(s.buf[1]);
         if (s.copy_stream) (void)hipStreamDestroy(s.copy_stream);
+        if (s.ev_copy) (void)hipEventDestroy(s.ev_copy);
     }
     for (auto e : c->prof_ev) (void)hipEventDestroy(e);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
@@ -252,7 +279,7 @@ void free_all(cm_ctx* c) {
 }
 
 int set_slot_cloud(cm_ctx* c, uint32_t sensor, const void* data, bool on_device, uint32_t n,
-                   uint32_t step, uint32_t ox, uint32_t oy, uint32_t oz, uint32_t oi) {
+                   uint32_t step, uint32_t ox, uint32_t oy, uint32_t oz, uint32_t oi, bool wait_copy = true) {
     if (!c) return CM_BAD_ARG;
     if (sensor >= c->max_sensors) return fail(c, CM_BAD_ARG, "sensor index out of range");
     if (n && !data) return fail(c, CM_BAD_ARG, "null payload");
@@ -264,27 +291,39 @@ int set_slot_cloud(cm_ctx* c, uint32_t sensor, const void* data, bool on_device,
     Slot& s = c->slots[sensor];
     std::lock_guard<std::mutex> lk(s.mu);
     if (s.fresh && !(c->flags & CM_FLAG_LATEST_WINS)) return CM_SKIPPED;   // first since last fuse wins
-    if (c->in_flight.load()) HIP_TRY(c, hipEventSynchronize(c->ev_done));
     const size_t bytes = static_cast<size_t>(n) * step;
+    SlotCloud sc;
+    sc.n = n; sc.step = step; sc.ox = ox; sc.oy = oy; sc.oz = oz; sc.oi = oi;
     if (on_device) {
-        s.dptr = data;
+        sc.dptr = data;
+        s.bytes_h2d = 0;
     } else {
-        if (bytes > s.dcap) {
-            if (s.dbuf) HIP_TRY(c, hipFree(s.dbuf));
-            s.dbuf = nullptr; s.dcap = 0;
+        // the buffer no enqueued frame reads (a replaced staged cloud lived there too: same copy stream, in order)
+        const int w = s.active_buf == 0 ? 1 : 0;
+        if (bytes > s.cap[w]) {
+            if (s.buf[w]) HIP_TRY(c, hipFree(s.buf[w]));
+            s.buf[w] = nullptr; s.cap[w] = 0;
             const size_t cap = bytes + bytes / 4 + 256;
-            HIP_TRY(c, hipMalloc(&s.dbuf, cap));
-            s.dcap = cap;
+            HIP_TRY(c, hipMalloc(&s.buf[w], cap));
+            s.cap[w] = cap;
         }
         if (bytes) {
-            HIP_TRY(c, hipMemcpyAsync(s.dbuf, data, bytes, hipMemcpyHostToDevice, s.copy_stream));
-            HIP_TRY(c, hipStreamSynchronize(s.copy_stream));
+            HIP_TRY(c, hipMemcpyAsync(s.buf[w], data, bytes, hipMemcpyHostToDevice, s.copy_stream));
+            if (wait_copy) {
+                HIP_TRY(c, hipStreamSynchronize(s.copy_stream));     // the caller may release `data` when this returns
+                s.copy_pending = false;
+            } else {
+                HIP_TRY(c, hipEventRecord(s.ev_copy, s.copy_stream));  // the frame that consumes the cloud waits for it
+                s.copy_pending = true;
+            }
         }
-        s.dptr = s.dbuf;
+        sc.dptr = s.buf[w];
+        s.bytes_h2d = bytes;
     }
-    s.n = n; s.step = step; s.ox = ox; s.oy = oy; s.oz = oz; s.oi = oi;
+    s.staged = sc;
     s.has_data = true;
     s.fresh = true;
+    ++s.gen;
     return CM_OK;
 }
 
@@ -306,22 +345,51 @@ int build_frame(cm_ctx* c, const cm_params* p, bool consume, std::vector<std::un
     std::memset(&f, 0, sizeof f);
     uint32_t base = 0, k = 0;
     uint64_t n_in = 0;
+    // the clouds the frame will read: a slot's staged cloud if it has a fresh one, else the one its last frame read
+    // (a stale optional sensor rides along like :141)
     for (uint32_t s = 0; s < c->max_sensors; ++s) {
         Slot& sl = c->slots[s];
-        if (!sl.has_data) continue;          // stale optional sensors ride along like :141
-        CmSensorDev& d = f.s[k++];
-        d.data = static_cast<const unsigned char*>(sl.dptr);
-        d.n = sl.n; d.base = base; d.point_step = sl.step; d.slot = s;
-        d.off_x = sl.ox; d.off_y = sl.oy; d.off_z = sl.oz; d.off_i = sl.oi;
-        const bool al16 = (reinterpret_cast<uintptr_t>(sl.dptr) & 15u) == 0;
-        if (al16 && sl.step == 16 && sl.ox == 0 && sl.oy == 4 && sl.oz == 8 && sl.oi == 12) d.layout = CM_LAYOUT_XYZI16;
-        else if (al16 && sl.step == 32 && sl.ox == 0 && sl.oy == 4 && sl.oz == 8 && sl.oi == 16) d.layout = CM_LAYOUT_PCL32;
-        else d.layout = CM_LAYOUT_GENERIC;
-        std::memcpy(d.m, sl.m, sizeof d.m);
-        n_in += sl.n;
-        const uint64_t nb = static_cast<uint64_t>(base) + round_up(sl.n, CM_TILE);
+        if (!sl.has_data) continue;
+        const uint64_t nb = static_cast<uint64_t>(base) + round_up(sl.fresh ? sl.staged.n : sl.active.n, CM_TILE);
         if (nb > c->cap_padded) return fail(c, CM_CAPACITY, "frame exceeds cm_limits.max_points_total");
         base = static_cast<uint32_t>(nb);
+    }
+    base = 0;
+    c->stats_n_sensors = 0;
+    for (uint32_t s = 0; s < c->max_sensors; ++s) {
+        Slot& sl = c->slots[s];
+        if (!sl.has_data) continue;
+        if (sl.fresh) {
+            // an H2D copy enqueued without waiting (cm_submit_cloud_async): the frame's stream waits for it, not the host
+            if (sl.copy_pending) HIP_TRY(c, hipStreamWaitEvent(c->stream, sl.ev_copy, 0));
+            if (consume) {                   // the frame takes the staged cloud over; submits now go to the other buffer
+                sl.active = sl.staged;
+                sl.active_buf = sl.staged.dptr == sl.buf[0] ? 0 : sl.staged.dptr == sl.buf[1] ? 1 : -1;
+                sl.active_bytes_h2d = sl.bytes_h2d;
+                sl.active_gen = sl.gen;
+                sl.copy_pending = false;
+            }
+        }
+        const SlotCloud& sc = (sl.fresh && !consume) ? sl.staged : sl.active;   // (!consume: cm_local_bounds' peek)
+        CmSensorDev& d = f.s[k];
+        d.data = static_cast<const unsigned char*>(sc.dptr);
+        d.n = sc.n; d.base = base; d.point_step = sc.step; d.slot = s;
+        d.off_x = sc.ox; d.off_y = sc.oy; d.off_z = sc.oz; d.off_i = sc.oi;
+        const bool al16 = (reinterpret_cast<uintptr_t>(sc.dptr) & 15u) == 0;
+        if (al16 && sc.step == 16 && sc.ox == 0 && sc.oy == 4 && sc.oz == 8 && sc.oi == 12) d.layout = CM_LAYOUT_XYZI16;
+        else if (al16 && sc.step == 32 && sc.ox == 0 && sc.oy == 4 && sc.oz == 8 && sc.oi == 16) d.layout = CM_LAYOUT_PCL32;
+        else d.layout = CM_LAYOUT_GENERIC;
+        std::memcpy(d.m, sl.m, sizeof d.m);
+        n_in += sc.n;
+        if (consume) {
+            c->stats_sensor[k] = s; c->stats_n[k] = sc.n;
+            c->stats_fresh[k] = sl.fresh ? 1u : 0u;
+            c->stats_bytes[k] = sl.fresh ? sl.active_bytes_h2d : 0u;
+            c->stats_gen[k] = sl.active_gen;
+            c->stats_n_sensors = k + 1;
+        }
+        ++k;
+        base += round_up(sc.n, CM_TILE);
     }
     f.n_sensors = k;
     f.n_padded = base;
@@ -477,7 +545,7 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
         cmk2_scatter(st, pass == 0, c->d_frame, c->d_tiles, state, in, out, c->dig, c->hist, grp, big ? c->totals : nullptr,
                      low_bits + 8 * pass, pass + 1 < n_global ? low_bits + 8 * (pass + 1) : 32u, nt, n_groups,
                      f.n_padded, c->records, nt, predicted ? 1 : 0, mask, 0, (pack && pass == 0) ? c->rec_b : nullptr, c->wave_cnt,
-                     (c->debug_misrank && pass + 1 == n_global) ? 1 : 0);
+                     (c->debug_misrank && pass + 1 == n_global) ? 1 : 0, c->d_tile_kept);
     }
     const void* rec_sorted = ((n_global - 1) & 1u) ? c->rec_b : c->rec_a;
     c->last_k3 = c->finish_mode != 2;
@@ -565,6 +633,7 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
     c->out_is_merged = false;
     c->prof_used = 0;
     c->last_mode = mode;
+    c->bytes_d2h = 0;
 
     if (f.n_padded == 0) {                             // every submitted cloud is empty
         c->frame_had_ground = c->ground_on && mode == 0;   // ... so are the ground cloud and every slab (no stale planes)
@@ -690,7 +759,7 @@ int launch_classic(cm_ctx* c, const cm_params* p, int mode, int grid_mode, uint3
             if (big) { prof_mark(c, "k_gscan"); cmk_gscan(st, stg, grp, c->totals, pass, n_groups); }
             prof_mark(c, "k_scatter");
             cmk_scatter(st, stg, kin, vin, kout, vout, c->hist, grp, big ? c->totals : nullptr, pass, nt,
-                        n_groups, f.n_padded, c->lds_rank);
+                        n_groups, f.n_padded, c->lds_rank, use_cell ? nullptr : c->d_tile_kept);
         }
     };
 
@@ -872,23 +941,15 @@ int wait_frame(cm_ctx* c, cm_result* res) {
                 c->last_v2 = false;
                 c->last_predicted = false;
                 {
-                    // Re-assemble from the slots (a sensor may have delivered a newer cloud meanwhile: whole
-                    // clouds only, never a torn one) and hold them until the kernels are enqueued, as enqueue does.
-                    std::vector<std::unique_lock<std::mutex>> locks;
+                    // The frame's clouds are still where they were: a slot's active buffer is not written to before the
+                    // next frame is enqueued, whatever the subscriber threads submit meanwhile. Same descriptor, general kernels.
                     const cm_params pr = c->last_params;
-                    const CmFrameDev prev = c->frame;          // what enqueue derived from the parameters stays
-                    int e = build_frame(c, &pr, false, locks, false);
-                    for (int a = 0; a < 3; ++a) c->frame.inv_cell[a] = prev.inv_cell[a];
-                    c->frame.outlier_r2 = prev.outlier_r2;
-                    c->frame.outlier_min_nb = prev.outlier_min_nb;
-                    for (int a = 0; a < 3; ++a) { c->frame.ext_min[a] = prev.ext_min[a]; c->frame.ext_max[a] = prev.ext_max[a]; }
                     c->post_bucket = false;
                     c->pre_bucket = false;
-                    if (e == CM_OK && c->frame.n_padded)
-                        e = launch_classic(c, &pr, c->last_mode, c->last_grid_mode, c->last_key_bits, c->last_outl, c->last_gm_o, c->last_kb_o);
-                    else if (e == CM_OK)
-                        e = CM_NOT_READY;
-                    if (e != CM_OK) { c->pending = false; return e == CM_NOT_READY ? fail(c, CM_INTERNAL, "frame could not be redone: its clouds were cleared") : e; }
+                    int e = c->frame.n_padded ? launch_classic(c, &pr, c->last_mode, c->last_grid_mode, c->last_key_bits, c->last_outl,
+                                                               c->last_gm_o, c->last_kb_o)
+                                              : CM_INTERNAL;
+                    if (e != CM_OK) { c->pending = false; return e == CM_INTERNAL ? fail(c, CM_INTERNAL, "frame could not be redone") : e; }
                 }
                 HIP_TRY(c, hipEventSynchronize(c->ev_done));
                 c->in_flight.store(false);
@@ -1045,12 +1106,15 @@ int cm_create(cm_ctx** out, int device, const cm_limits* lim) {
         ok = ok && A(reinterpret_cast<void**>(&c->out_key), n4) && A(reinterpret_cast<void**>(&c->out_cnt), n4);
     ok = ok && A(reinterpret_cast<void**>(&c->d_frame), sizeof(CmFrameDev));
     ok = ok && A(reinterpret_cast<void**>(&c->d_tiles), static_cast<size_t>(c->cap_tiles) * sizeof(CmTileDev));
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_tile_kept), static_cast<size_t>(c->cap_tiles) * 4, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_tile_kept), c->h_tile_kept, 0) == hipSuccess;
     ok = ok && A(reinterpret_cast<void**>(&c->d_state[0]), sizeof(CmFrameState));
     ok = ok && A(reinterpret_cast<void**>(&c->d_state[1]), sizeof(CmFrameState));
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_state), sizeof(CmFrameState), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_state_dev), c->h_state, 0) == hipSuccess;
     for (uint32_t s = 0; ok && s < c->max_sensors; ++s)
-        ok = hipStreamCreateWithFlags(&c->slots[s].copy_stream, hipStreamNonBlocking) == hipSuccess;
+        ok = hipStreamCreateWithFlags(&c->slots[s].copy_stream, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&c->slots[s].ev_copy, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMemset(c->d_state[0], 0, sizeof(CmFrameState)) == hipSuccess;
     ok = ok && hipMemset(c->d_state[1], 0, sizeof(CmFrameState)) == hipSuccess;
     ok = ok && hipDeviceSynchronize() == hipSuccess;
@@ -1133,6 +1197,11 @@ int cm_submit_cloud(cm_ctx* c, uint32_t sensor, const void* host_data, uint32_t 
     return set_slot_cloud(c, sensor, host_data, false, n, point_step, off_x, off_y, off_z, off_i);
 }
 
+int cm_submit_cloud_async(cm_ctx* c, uint32_t sensor, const void* host_data, uint32_t n, uint32_t point_step,
+                          uint32_t off_x, uint32_t off_y, uint32_t off_z, uint32_t off_i) {
+    return set_slot_cloud(c, sensor, host_data, false, n, point_step, off_x, off_y, off_z, off_i, false);
+}
+
 int cm_submit_cloud_device(cm_ctx* c, uint32_t sensor, const void* dev_data, uint32_t n, uint32_t point_step,
                            uint32_t off_x, uint32_t off_y, uint32_t off_z, uint32_t off_i) {
     return set_slot_cloud(c, sensor, dev_data, true, n, point_step, off_x, off_y, off_z, off_i);
@@ -1144,7 +1213,7 @@ int cm_clear_sensor(cm_ctx* c, uint32_t sensor) {
     std::lock_guard<std::mutex> lk(c->slots[sensor].mu);
     c->slots[sensor].has_data = false;
     c->slots[sensor].fresh = false;
-    c->slots[sensor].n = 0;
+    c->slots[sensor].staged = SlotCloud();       // (the buffers stay: a frame in flight may still read the active one)
     return CM_OK;
 }
 
@@ -1191,6 +1260,7 @@ int cm_result_copy(cm_ctx* c, void* host_dst, uint64_t capacity_points, uint32_t
     if (n == 0) return CM_OK;
     if (!host_dst) return CM_BAD_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
+    c->bytes_d2h += n * 16;
     if (step_out == 16) {
         HIP_TRY(c, hipMemcpyAsync(host_dst, c->out, n * 16, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1205,6 +1275,54 @@ int cm_result_copy(cm_ctx* c, void* host_dst, uint64_t capacity_points, uint32_t
         d[8 * i + 3] = 1.0f; d[8 * i + 4] = tmp[4 * i + 3];
         d[8 * i + 5] = d[8 * i + 6] = d[8 * i + 7] = 0.0f;
     }
+    return CM_OK;
+}
+
+int cm_result_copy_async(cm_ctx* c, void* host_dst, uint64_t capacity_points) {
+    if (!c) return CM_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->merge_mu);
+    if (!c->have_result) return fail(c, CM_BAD_ARG, "no result");
+    const uint64_t n = c->result.n_out;
+    if (n > capacity_points) return fail(c, CM_CAPACITY, "destination too small");
+    if (n == 0) return CM_OK;
+    if (!host_dst) return CM_BAD_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(host_dst, c->out, n * 16, hipMemcpyDeviceToHost, c->stream));
+    c->bytes_d2h += n * 16;
+    return CM_OK;
+}
+
+int cm_sync(cm_ctx* c) {
+    if (!c) return CM_BAD_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CM_OK;
+}
+
+int cm_get_frame_stats(cm_ctx* c, cm_frame_stats* out) {
+    if (!c || !out) return CM_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->merge_mu);
+    if (!c->have_result) return fail(c, CM_BAD_ARG, "no result");
+    std::memset(out, 0, sizeof *out);
+    out->n_sensors = c->stats_n_sensors;
+    const uint32_t* kept = c->h_tile_kept;                 // (written by the frame's first scatter; the frame has been waited for)
+    const bool have_kept = c->result.status == CM_OK && c->frame.n_tiles && c->last_mode != 2;
+    for (uint32_t k = 0; k < c->stats_n_sensors; ++k) {
+        out->sensor[k] = c->stats_sensor[k];
+        out->n_in[k] = c->stats_n[k];
+        out->fresh[k] = c->stats_fresh[k];
+        out->bytes_h2d[k] = c->stats_bytes[k];
+        out->generation[k] = c->stats_gen[k];
+        out->bytes_h2d_total += c->stats_bytes[k];
+        if (have_kept) {
+            const uint32_t t0 = c->frame.s[k].base / CM_TILE, t1 = t0 + (c->frame.s[k].n + CM_TILE - 1) / CM_TILE;
+            uint64_t sum = 0;
+            for (uint32_t t = t0; t < t1 && t < c->frame.n_tiles; ++t) sum += kept[t];
+            out->n_kept[k] = static_cast<uint32_t>(sum);
+        }
+    }
+    out->bytes_d2h_total = c->bytes_d2h;
+    out->bytes_algorithmic = 16ull * c->result.n_in + 16ull * c->result.n_out;
     return CM_OK;
 }
 
@@ -1258,6 +1376,7 @@ int cm_merged_copy(cm_ctx* c, void* host_dst, uint64_t capacity, uint64_t* n_poi
     if (total && host_dst) {
         HIP_TRY(c, hipMemcpyAsync(host_dst, c->merged, static_cast<size_t>(total) * 16, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->bytes_d2h += static_cast<uint64_t>(total) * 16;
     }
     return CM_OK;
 }

@@ -24,7 +24,7 @@ void cmk_gscan(hipStream_t s, const CmFrameState* st, uint32_t* grp, uint32_t* t
 void cmk_scatter(hipStream_t s, CmFrameState* st, const uint32_t* keys_in, const uint32_t* vals_in,
                  uint32_t* keys_out, uint32_t* vals_out, const uint32_t* hist, const uint32_t* grp,
                  const uint32_t* totals, uint32_t pass, uint32_t n_tiles, uint32_t n_groups,
-                 uint32_t n_padded, bool lds_rank);
+                 uint32_t n_padded, bool lds_rank, uint32_t* tile_kept = nullptr);
 void cmk_probe_lds_order(hipStream_t s, uint32_t* violations, uint32_t rounds);
 void cmk_seg_count(hipStream_t s, CmFrameState* st, const uint32_t* keys_a, const uint32_t* keys_b,
                    uint32_t* counts, uint32_t* group_counts, uint32_t min_pts, uint32_t n_seg_tiles);
@@ -55,7 +55,8 @@ void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, const CmTileD
                   unsigned char* dig_out, const uint32_t* hist, const uint32_t* grp, const uint32_t* totals,
                   uint32_t shift, uint32_t next_shift, uint32_t n_tiles, uint32_t n_groups, uint32_t n_padded,
                   const float* records, uint32_t n_records, int fold, const unsigned char* mask, int use_cell = 0,
-                  const void* compact_in = nullptr, const uint32_t* wave_cnt = nullptr, int debug_swap = 0);
+                  const void* compact_in = nullptr, const uint32_t* wave_cnt = nullptr, int debug_swap = 0,
+                  uint32_t* tile_kept = nullptr);
 void cmk2_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next, uint32_t* host_state,
                 const void* rec, unsigned long long* tile_state, uint32_t* ticket, void* out, uint32_t* out_key,
                 uint32_t* out_cnt, void* partial_out, uint32_t low_bits, uint32_t n_padded);

@@ -344,7 +344,8 @@ __global__ __launch_bounds__(CM_BLOCK, 4) void k_scatter(CmFrameState* __restric
                                                       const uint32_t* __restrict__ hist,
                                                       const uint32_t* __restrict__ grp,
                                                       const uint32_t* __restrict__ totals,
-                                                      uint32_t pass, uint32_t n_groups, uint32_t n_padded) {
+                                                      uint32_t pass, uint32_t n_groups, uint32_t n_padded,
+                                                      uint32_t* __restrict__ tile_kept) {
     __shared__ uint32_t whist[CM_WAVES][CM_RADIX];
     __shared__ uint32_t gofs[CM_RADIX];
     __shared__ uint32_t skey[CM_TILE];
@@ -473,6 +474,7 @@ __global__ __launch_bounds__(CM_BLOCK, 4) void k_scatter(CmFrameState* __restric
     __syncthreads();
 
     const uint32_t tile_valid = s_tile_valid;
+    if (FIRST && tile_kept && threadIdx.x == 0) tile_kept[tile] = tile_valid;   // cm_get_frame_stats: points per sensor that entered the grid
 #pragma unroll
     for (int j = 0; j < CM_ITEMS; ++j) {
         const uint32_t t = j * CM_BLOCK + threadIdx.x;
@@ -1318,21 +1320,21 @@ void cmk_gscan(hipStream_t s, const CmFrameState* st, uint32_t* grp, uint32_t* t
 void cmk_scatter(hipStream_t s, CmFrameState* st, const uint32_t* keys_in, const uint32_t* vals_in,
                  uint32_t* keys_out, uint32_t* vals_out, const uint32_t* hist, const uint32_t* grp,
                  const uint32_t* totals, uint32_t pass, uint32_t n_tiles, uint32_t n_groups,
-                 uint32_t n_padded, bool lds_rank) {
+                 uint32_t n_padded, bool lds_rank, uint32_t* tile_kept) {
     if (pass == 0) {
         if (lds_rank)
             CM_LAUNCH((k_scatter<true, true>), n_tiles, CM_BLOCK, s, st, keys_in, vals_in, keys_out, vals_out,
-                      hist, grp, totals, pass, n_groups, n_padded);
+                      hist, grp, totals, pass, n_groups, n_padded, tile_kept);
         else
             CM_LAUNCH((k_scatter<true, false>), n_tiles, CM_BLOCK, s, st, keys_in, vals_in, keys_out, vals_out,
-                      hist, grp, totals, pass, n_groups, n_padded);
+                      hist, grp, totals, pass, n_groups, n_padded, tile_kept);
     } else {
         if (lds_rank)
             CM_LAUNCH((k_scatter<false, true>), n_tiles, CM_BLOCK, s, st, keys_in, vals_in, keys_out, vals_out,
-                      hist, grp, totals, pass, n_groups, n_padded);
+                      hist, grp, totals, pass, n_groups, n_padded, tile_kept);
         else
             CM_LAUNCH((k_scatter<false, false>), n_tiles, CM_BLOCK, s, st, keys_in, vals_in, keys_out, vals_out,
-                      hist, grp, totals, pass, n_groups, n_padded);
+                      hist, grp, totals, pass, n_groups, n_padded, tile_kept);
     }
 }
 void cmk_probe_lds_order(hipStream_t s, uint32_t* violations, uint32_t rounds) {

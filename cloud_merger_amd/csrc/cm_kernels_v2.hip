@@ -306,7 +306,8 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __r
                                                            uint32_t n_records, int fold,
                                                            const unsigned char* __restrict__ mask, int use_cell,
                                                            const float4* __restrict__ compact_in,
-                                                           const uint32_t* __restrict__ wave_cnt, int debug_swap) {
+                                                           const uint32_t* __restrict__ wave_cnt, int debug_swap,
+                                                           uint32_t* __restrict__ tile_kept) {
     // debug_swap (tests only, CM_DEBUG_MISRANK=1): the first and the last record of tile 0's sorted tile change places on
     // their way out — what a mis-ranked pass would look like to the finish, which must notice (CM_DEV_ERR_UNSORTED).
     // 37 KB of LDS and at most 64 VGPRs: four workgroups per CU, so that the 977 tiles of a 4 M-point frame are all
@@ -374,7 +375,10 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __r
         uint32_t tile_cnt = 0;
 #pragma unroll
         for (int q = 0; q < CM2_WAVES; ++q) tile_cnt += wave_cnt[tile * CM2_WAVES + q];
-        if (tile_cnt == 0 && tile != 0) return;            // nothing of this tile survived (tile 0 also records the frame's totals)
+        if (tile_cnt == 0 && tile != 0) {                  // nothing of this tile survived (tile 0 also records the frame's totals)
+            if (tile_kept && threadIdx.x == 0) tile_kept[tile] = 0;
+            return;
+        }
         const uint32_t cw = wave_cnt[tile * CM2_WAVES + w];
         const float4* __restrict__ src = compact_in + static_cast<size_t>(tile) * CM_TILE + w * (64 * CM2_ITEMS);
 #pragma unroll
@@ -469,6 +473,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __r
     if (threadIdx.x < CM_RADIX)                                  // (read again behind the barrier of the first staging round)
         gofs[threadIdx.x] = gbase + before + gofs[threadIdx.x] - s_dbase[threadIdx.x];   // (+ the part threads 256-511 summed)
     const uint32_t tile_valid = s_tile_valid;
+    if (FIRST && tile_kept && threadIdx.x == 0) tile_kept[tile] = tile_valid;   // cm_get_frame_stats: points per sensor that entered the grid
 #pragma unroll
     for (int r = 0; r < CM2_ITEMS; ++r) {
         const uint32_t digit = lp[r] & 0xFFu;
@@ -965,17 +970,17 @@ void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, const CmTileD
                   unsigned char* dig_out, const uint32_t* hist, const uint32_t* grp, const uint32_t* totals,
                   uint32_t shift, uint32_t next_shift, uint32_t n_tiles, uint32_t n_groups, uint32_t n_padded,
                   const float* records, uint32_t n_records, int fold, const unsigned char* mask, int use_cell,
-                  const void* compact_in, const uint32_t* wave_cnt, int debug_swap) {
+                  const void* compact_in, const uint32_t* wave_cnt, int debug_swap, uint32_t* tile_kept) {
     const float4* in = reinterpret_cast<const float4*>(rec_in);
     float4* o = reinterpret_cast<float4*>(rec_out);
     if (first)
         hipLaunchKernelGGL(k2_scatter<true>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, in, o, dig_out, hist, grp,
                            totals, shift, next_shift, n_groups, n_padded, records, n_records, fold, mask, use_cell,
-                           reinterpret_cast<const float4*>(compact_in), wave_cnt, debug_swap);
+                           reinterpret_cast<const float4*>(compact_in), wave_cnt, debug_swap, tile_kept);
     else
         hipLaunchKernelGGL(k2_scatter<false>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, in, o, dig_out, hist, grp,
                            totals, shift, next_shift, n_groups, n_padded, records, n_records, fold, mask, use_cell,
-                           reinterpret_cast<const float4*>(compact_in), wave_cnt, debug_swap);
+                           reinterpret_cast<const float4*>(compact_in), wave_cnt, debug_swap, tile_kept);
 }
 void cmk2_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next, uint32_t* host_state,
                 const void* rec, unsigned long long* tile_state, uint32_t* ticket, void* out, uint32_t* out_key,

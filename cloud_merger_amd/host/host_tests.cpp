@@ -1,9 +1,12 @@
 // host_tests.cpp — CPU-side checks of the host shell (no GPU needed): PointCloud2 field lookup,
 // PCD round trip, the reference's literals in reference_config(), and that the node fails loudly
 // (no fallback) when no MI355X is present. Exit code 0 = all passed. Run by tests/test_host_shell.py.
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 
 #include "merger_node.hpp"
 #include "pcd_io.hpp"
@@ -69,6 +72,37 @@ static void test_pcd_roundtrip(const char* tmpdir) {
     std::memcpy(&z1, a.data.data() + 12 + 8, 4);
     CHECK(std::isnan(z1));
     CHECK(!read_pcd(std::string(tmpdir) + "/missing.pcd", &a, &err));
+    // what pcl_ros pointcloud_to_pcd writes for pcl::PointXYZI (padding fields) and a Velodyne cloud (ring: U2)
+    const std::string ppath = std::string(tmpdir) + "/padded.pcd";
+    f = std::fopen(ppath.c_str(), "wb");
+    std::fprintf(f, "# .PCD v0.7\nVERSION 0.7\nFIELDS x y z _ intensity _ ring\nSIZE 4 4 4 1 4 1 2\nTYPE F F F U F U U\nCOUNT 1 1 1 4 1 10 1\n"
+                    "WIDTH 2\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS 2\nDATA binary\n");
+    for (int i = 0; i < 2; ++i) {
+        unsigned char row[32] = {0};
+        const float xyz[3] = {1.0f + i, 2.0f + i, 3.0f + i}, inten = 40.0f + i;
+        const uint16_t ring = static_cast<uint16_t>(7 + i);
+        std::memcpy(row, xyz, 12); std::memcpy(row + 16, &inten, 4); std::memcpy(row + 30, &ring, 2);
+        std::fwrite(row, 1, 32, f);
+    }
+    std::fclose(f);
+    PointCloud2 pd;
+    CHECK(read_pcd(ppath, &pd, &err));
+    const XyziLayout pl = find_xyzi(pd);
+    CHECK(pd.num_points() == 2 && pd.point_step == 32 && pl.ok && pl.off_x == 0 && pl.off_i == 16 && pd.fields.size() == 5);
+    CHECK(pd.fields.back().name == "ring" && pd.fields.back().offset == 30 && pd.fields.back().datatype == PointField::UINT16);
+    float i1; std::memcpy(&i1, pd.data.data() + 32 + 16, 4);
+    CHECK(i1 == 41.0f);
+    // headers that lie: more points than the file holds, a zero / negative COUNT, an unknown type
+    const char* bad[3] = {"FIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 4000000000\nHEIGHT 1\nPOINTS 4000000000\nDATA binary\n",
+                          "FIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 -1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA ascii\n1 2 3\n",
+                          "FIELDS x y z\nSIZE 4 4 3\nTYPE F F Q\nCOUNT 1 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA ascii\n1 2 3\n"};
+    for (int k = 0; k < 3; ++k) {
+        const std::string bpath = std::string(tmpdir) + "/bad" + std::to_string(k) + ".pcd";
+        f = std::fopen(bpath.c_str(), "w");
+        std::fprintf(f, "VERSION 0.7\n%s", bad[k]);
+        std::fclose(f);
+        CHECK(!read_pcd(bpath, &pd, &err));
+    }
 }
 
 static void test_reference_config() {
@@ -96,6 +130,7 @@ static void test_reference_config() {
     CHECK(l.ground.zones[4][1].z_max_ground < 0.0f && l.ground.zones[4][1].x_min == -15.0f && l.ground.zones[4][1].x_length == 35.0f);
     CHECK(l.ground.zones[5][0].x_min == 34.0f && l.ground.zones[5][3].x_min == 4.0f && l.ground.zones[5][3].z_max_ground == 0.5f);
     CHECK(l.no_ground_topic == "/points_no_ground" && l.ground_topic == "/points_ground");
+    CHECK(l.ground.outlier_radius == 0.15f && l.ground.outlier_min_neighbors == 1);      // removeGround's outlierRemoval, :119 / Parameter.h:23-24
     const NodeConfig f = fusion_config();
     CHECK(f.params.outlier_enable == 1 && f.params.outlier_radius == 0.1f && f.params.outlier_min_neighbors == 1);
     CHECK(f.sensors.size() == 6 && f.params.crop_enable == 1);
@@ -118,6 +153,17 @@ static void test_load_config(const char* tmpdir) {
     CHECK(c.stamp_from_inputs && c.rate_hz == 20.0 && c.voxel_topic == "/voxels" && c.max_points_total == 123456);
     CHECK(c.max_stamp_spread_ns == 25000000ull);
     CHECK(c.base_frame == "base_footprint");                      // untouched keys keep the reference's values
+    // ground keys: roi_z_max follows the crop box whichever line comes first; the slab filter's radius has its own key
+    for (int order = 0; order < 2; ++order) {
+        f = std::fopen(path.c_str(), "w");
+        std::fprintf(f, order == 0 ? "ground 500 0.2 0.9\ncrop -1 -2 -3 4 5 6.5\nground_outlier 0.15 1\nzone front_right 0 10 0.5\n"
+                                   : "crop -1 -2 -3 4 5 6.5\nground_outlier 0.15 1\nground 500 0.2 0.9\nzone front_right 0 10 0.5\n");
+        std::fclose(f);
+        NodeConfig g;
+        CHECK(load_config(path, &g, &err));
+        CHECK(g.ground_enable && g.ground.max_iterations == 500 && g.ground.z_keep_max == 6.5f && g.ground.n_zones[0] == 1);
+        CHECK(g.ground.outlier_radius == 0.15f && g.ground.outlier_min_neighbors == 1);
+    }
     f = std::fopen(path.c_str(), "w");
     std::fprintf(f, "leaf -1\n");
     std::fclose(f);
@@ -208,6 +254,42 @@ static void test_node_without_gpu_fails_loudly(bool expect_gpu) {
         CHECK(n4.on_cloud(0, cg) == CM_OK);
         CHECK(n4.spin_once() == CM_OK);
         CHECK(n_gr == 100 && n_ng == 4 && n_vox == 1);
+        // a subscriber thread keeps delivering clouds — of two sizes, the larger one forcing the slot to
+        // allocate — while the loop fuses and then reads the frame's by-products (cm_merged_copy, cm_ground_copy). Every
+        // published triple must belong to ONE of the two clouds: ground + no-ground = that cloud's points.
+        {
+            c4.flags = CM_FLAG_LATEST_WINS;
+            c4.max_points_total = 40000;
+            CloudMergerNode n5(c4);
+            CHECK(n5.ok());
+            n5.set_transform(0, q, t);
+            PointCloud2 big = make_xyzi16_message(104 + 30000);
+            std::memcpy(big.data.data(), cg.data.data(), 104 * 16);
+            for (int i = 0; i < 30000; ++i) {                             // a wall of points above the band: all "no ground"
+                const float rec[4] = {1.0f + 0.0002f * i, -3.0f + 0.0001f * i, 2.0f + 0.00001f * i, 3.f};
+                std::memcpy(big.data.data() + (104 + i) * 16, rec, 16);
+            }
+            std::atomic<bool> stop{false};
+            std::atomic<int> submits{0};
+            std::thread feeder([&] {
+                for (int k = 0; !stop.load(); ++k) {
+                    if (n5.on_cloud(0, (k & 1) ? big : cg) == CM_OK) submits.fetch_add(1);
+                    std::this_thread::sleep_for(std::chrono::microseconds(150));     // (a sensor, not a lock-hogging loop)
+                }
+            });
+            size_t ng = 0, gr = 0; int bad = 0, frames = 0, bigs = 0;
+            n5.set_publisher([&](const std::string& topic, const PointCloud2& out) {
+                if (topic == "/points_no_ground") ng = out.num_points();
+                else if (topic == "/points_ground") gr = out.num_points();
+                else { ++frames; const size_t tot = ng + gr; if (tot != 104 && tot != 30104) ++bad; if (tot == 30104) ++bigs; if (gr != 100) ++bad; }
+            });
+            const auto t_end = std::chrono::steady_clock::now() + std::chrono::seconds(10);
+            while (frames < 300 && std::chrono::steady_clock::now() < t_end) (void)n5.spin_once();   // (NOT_READY until the feeder delivers)
+            stop.store(true);
+            feeder.join();
+            CHECK(bad == 0 && frames > 50 && bigs > 5 && submits.load() > frames);
+            if (bad || frames <= 50 || bigs <= 5) std::printf("  bad %d frames %d bigs %d submits %d last ng %zu gr %zu err '%s'\n", bad, frames, bigs, submits.load(), ng, gr, n5.error().c_str());
+        }
     } else {
         CHECK(!node.ok() && !node.error().empty());
         CHECK(node.spin_once() == CM_NO_DEVICE);

@@ -44,6 +44,8 @@ NodeConfig live_node_config() {
     g.probability = 0.99f;                         // :41
     g.optimize_coefficients = 1;                   // :95
     g.z_keep_max = 3.0f;                           // roi_z_max, :35
+    g.outlier_radius = 0.15f;                      // removeGround's outlierRemoval(no_ground_cloud_ptr), :119 — radius_search, Parameter.h:23
+    g.outlier_min_neighbors = 1;                   // min_neighbor, Parameter.h:24
     g.seed = 12345;
     const float roi_mid = 15.0f;
     // proceedFront (:228-269), in its processing order: front, mid2, mid, vehicle, rear (Parameter.h:45-55)
@@ -87,7 +89,7 @@ bool load_config(const std::string& path, NodeConfig* cfg, std::string* err) {
     std::ifstream f(path);
     if (!f) { if (err) *err = "cannot open " + path; return false; }
     NodeConfig c = reference_config();
-    bool own_sensors = false;
+    bool own_sensors = false, ground_z_from_crop = false;
     int lineno = 0;
     for (std::string line; std::getline(f, line);) {
         ++lineno;
@@ -118,8 +120,11 @@ bool load_config(const std::string& path, NodeConfig* cfg, std::string* err) {
         else if (key == "max_stamp_spread_ms") { double v; ok = static_cast<bool>(is >> v) && v >= 0; c.max_stamp_spread_ns = static_cast<uint64_t>(v * 1e6); }
         else if (key == "ground") {
             ok = static_cast<bool>(is >> c.ground.max_iterations >> c.ground.distance_threshold >> c.ground.probability);
-            c.ground.optimize_coefficients = 1; c.ground.z_keep_max = c.params.crop_max[2]; c.ground.seed = 12345;
+            c.ground.optimize_coefficients = 1; c.ground.seed = 12345;
+            ground_z_from_crop = true;                 // roi_z_max: taken from the crop box once the whole file is read
             c.ground_enable = true;
+        } else if (key == "ground_outlier") {
+            ok = static_cast<bool>(is >> c.ground.outlier_radius >> c.ground.outlier_min_neighbors) && c.ground.outlier_radius >= 0.0f;
         } else if (key == "zone") {
             std::string name; cm_zone z{};
             ok = static_cast<bool>(is >> name >> z.x_min >> z.x_length >> z.z_max_ground);
@@ -134,15 +139,18 @@ bool load_config(const std::string& path, NodeConfig* cfg, std::string* err) {
         if (!ok) { if (err) *err = path + ":" + std::to_string(lineno) + ": bad line"; return false; }
     }
     if (c.sensors.empty() || c.sensors.size() > CM_MAX_SENSORS) { if (err) *err = "sensor count must be 1..16"; return false; }
+    if (ground_z_from_crop) c.ground.z_keep_max = c.params.crop_max[2];     // (whichever of `crop` and `ground` came first)
     *cfg = c;
     return true;
 }
 
 CloudMergerNode::CloudMergerNode(const NodeConfig& cfg)
-    : cfg_(cfg), have_tf_(cfg.sensors.size()), stamp_ns_(cfg.sensors.size()), fresh_(cfg.sensors.size()) {
+    : cfg_(cfg), have_tf_(cfg.sensors.size()), stamp_ns_(cfg.sensors.size()), submitted_(cfg.sensors.size()),
+      consumed_(cfg.sensors.size()) {
     for (auto& f : have_tf_) f.store(false);
     for (auto& t : stamp_ns_) t.store(0);
-    for (auto& f : fresh_) f.store(false);
+    for (auto& f : submitted_) f.store(0);
+    for (auto& f : consumed_) f.store(0);
     if (cfg_.sensors.empty() || cfg_.sensors.size() > CM_MAX_SENSORS) {
         error_ = "sensor count must be 1..CM_MAX_SENSORS";
         return;
@@ -200,10 +208,10 @@ int CloudMergerNode::on_cloud(size_t sensor, const PointCloud2& msg) {
     if (!ctx_ || sensor >= cfg_.sensors.size()) return CM_BAD_ARG;
     if (!transforms_ready()) return CM_NOT_READY;
     const XyziLayout l = find_xyzi(msg);
-    if (!l.ok) { error_ = l.error; return CM_BAD_ARG; }
+    if (!l.ok) { set_error(l.error); return CM_BAD_ARG; }
     const int st = cm_submit_cloud(ctx_, static_cast<uint32_t>(sensor), msg.data.data(),
                                    static_cast<uint32_t>(msg.num_points()), msg.point_step, l.off_x, l.off_y, l.off_z, l.off_i);
-    if (st == CM_OK) { stamp_ns_[sensor].store(msg.header.stamp_ns); fresh_[sensor].store(true); }   // CM_SKIPPED: the slot keeps its older cloud
+    if (st == CM_OK) { stamp_ns_[sensor].store(msg.header.stamp_ns); submitted_[sensor].fetch_add(1); }   // CM_SKIPPED: the slot keeps its older cloud
     return st == CM_SKIPPED ? CM_OK : st;
 }
 
@@ -217,14 +225,14 @@ int CloudMergerNode::spin_once(cm_result* res) {
         size_t oldest = 0;
         for (size_t s = 0; s < cfg_.sensors.size(); ++s) {
             if (!cfg_.sensors[s].required) continue;
-            if (!fresh_[s].load()) { complete = false; break; }
+            if (!fresh(s)) { complete = false; break; }
             const uint64_t t = stamp_ns_[s].load();
             if (t < lo) { lo = t; oldest = s; }
             hi = std::max(hi, t);
         }
         if (complete && hi - lo > cfg_.max_stamp_spread_ns) {
             cm_clear_sensor(ctx_, static_cast<uint32_t>(oldest));
-            fresh_[oldest].store(false);
+            consumed_[oldest].store(submitted_[oldest].load());
             stamp_ns_[oldest].store(0);
             dropped_.fetch_add(1);
             return CM_NOT_READY;
@@ -234,14 +242,20 @@ int CloudMergerNode::spin_once(cm_result* res) {
     const int st = cm_merge_voxelize(ctx_, &cfg_.params, &r);      // fusePointclouds + voxelgrid
     if (res) *res = r;
     if (st == CM_NOT_READY) return st;                              // :575 — nothing fused this tick
-    if (st < 0) { error_ = cm_last_error(ctx_); return st; }
-    for (auto& f : fresh_) f.store(false);                          // flag reset, :151-157
+    if (st < 0) { set_error(cm_last_error(ctx_)); return st; }
+    {
+        // flag reset, :151-157 — for exactly the clouds this fuse read: a callback may have delivered the next one since
+        cm_frame_stats fs;
+        if (cm_get_frame_stats(ctx_, &fs) == CM_OK)
+            for (uint32_t k = 0; k < fs.n_sensors; ++k)
+                if (fs.sensor[k] < consumed_.size()) consumed_[fs.sensor[k]].store(fs.generation[k]);
+    }
     // publishPointcloud, voxel leg (:215-219): PCL layout, stamp = now, frame = base_footprint.
     PointCloud2 msg = cfg_.publish_pcl_layout ? make_pcl_xyzi_message(r.n_out) : make_xyzi16_message(r.n_out);
     if (st == CM_EMPTY_INPUT) { msg.width = 0; msg.height = 0; msg.row_step = 0; }   // A.4 step 1
     if (r.n_out) {
         const int cs = cm_result_copy(ctx_, msg.data.data(), r.n_out, msg.point_step);
-        if (cs != CM_OK) { error_ = cm_last_error(ctx_); return cs; }
+        if (cs != CM_OK) { set_error(cm_last_error(ctx_)); return cs; }
     }
     msg.header.seq = seq_++;
     uint64_t newest = 0;
@@ -254,7 +268,7 @@ int CloudMergerNode::spin_once(cm_result* res) {
             uint64_t n = 0;
             PointCloud2 m2 = make_xyzi16_message(static_cast<size_t>(r.n_in));
             const int cs = leg == 0 ? cm_merged_copy(ctx_, m2.data.data(), r.n_in, &n) : cm_ground_copy(ctx_, m2.data.data(), r.n_in, &n);
-            if (cs != CM_OK) { error_ = cm_last_error(ctx_); return cs; }
+            if (cs != CM_OK) { set_error(cm_last_error(ctx_)); return cs; }
             m2.width = static_cast<uint32_t>(n); m2.height = n ? 1 : 0; m2.row_step = static_cast<uint32_t>(n) * m2.point_step;
             m2.data.resize(static_cast<size_t>(n) * m2.point_step);
             m2.header = msg.header;

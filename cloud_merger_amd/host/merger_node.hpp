@@ -3,13 +3,13 @@
 // pcl_preprocessing/src/pc_preprocessing_main.cpp (main :509-587, callbacks :318-508) on top of
 // the C-ABI in include/cloudmerge.h; every numeric step runs in libcloudmerge_hip.so.
 //
-// What is deliberately NOT here: ROI zoning and RANSAC ground removal (:49-122, :228-312) —
-// SURVEY.md §8f "next" rows, outside the north-star path. Radius outlier removal on the fused cloud
-// (§8f rank 2) is available through cm_params.outlier_*.
+// The SURVEY.md §8f "next" rows ride on the same surface: zone-wise RANSAC ground removal (:49-122, :228-312;
+// live_node_config(), NodeConfig::ground*) and radius outlier removal on the fused cloud (cm_params.outlier_*).
 #pragma once
 #include <atomic>
 #include <cstdint>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -59,6 +59,7 @@ struct NodeConfig {
 //   crop <x0> <y0> <z0> <x1> <y1> <z1> | outlier <radius> <min_neighbors> | stamp_from_inputs <0|1>
 //   max_points_total <n> | device <n> | max_stamp_spread_ms <v>
 //   ground <max_iterations> <distance_threshold> <probability> | zone <sensor_name> <x_min> <x_length> <z_max_ground>
+//   ground_outlier <radius> <min_neighbors>   (removeGround's outlierRemoval on every slab's band points, :119)
 // Starts from reference_config() minus its sensors when the file names any. Returns false + *err.
 bool load_config(const std::string& path, NodeConfig* cfg, std::string* err);
 
@@ -85,7 +86,7 @@ public:
     CloudMergerNode& operator=(const CloudMergerNode&) = delete;
 
     bool ok() const { return ctx_ != nullptr; }
-    const std::string& error() const { return error_; }
+    std::string error() const { std::lock_guard<std::mutex> lk(err_mu_); return error_; }
     const NodeConfig& config() const { return cfg_; }
     int sensor_by_topic(const std::string& topic) const;
 
@@ -118,11 +119,16 @@ private:
     std::vector<std::atomic<bool>> have_tf_;
     Publisher publish_;
     Clock clock_;
+    mutable std::mutex err_mu_;                     // on_cloud runs on several threads at once
     std::string error_;
+    void set_error(const std::string& e) { std::lock_guard<std::mutex> lk(err_mu_); error_ = e; }
     std::atomic<uint64_t> frames_{0};
     uint32_t seq_ = 0;
     std::vector<std::atomic<uint64_t>> stamp_ns_;   // stamp of the cloud each sensor slot currently holds
-    std::vector<std::atomic<bool>> fresh_;          // slot holds a cloud that no fuse has consumed yet
+    // A slot holds a cloud no fuse has consumed yet when more submits were accepted for it than the last fuse had seen
+    // (cm_frame_stats.generation): exact, whichever way a callback and the fuse interleave.
+    std::vector<std::atomic<uint64_t>> submitted_, consumed_;
+    bool fresh(size_t s) const { return submitted_[s].load() > consumed_[s].load(); }
     std::atomic<uint64_t> dropped_{0};
 };
 

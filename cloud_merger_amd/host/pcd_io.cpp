@@ -3,6 +3,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <sstream>
 
@@ -17,11 +18,23 @@ std::vector<std::string> split(const std::string& line) {
 }
 }  // namespace
 
+// PCD TYPE/SIZE -> sensor_msgs/PointField datatype; 0: not a combination PCD defines.
+static uint8_t pcd_datatype(const std::string& type, unsigned size) {
+    if (type == "F") return size == 4 ? PointField::FLOAT32 : size == 8 ? PointField::FLOAT64 : 0;
+    if (type == "U") return size == 1 ? PointField::UINT8 : size == 2 ? PointField::UINT16 : size == 4 ? PointField::UINT32 : 0;
+    if (type == "I") return size == 1 ? PointField::INT8 : size == 2 ? PointField::INT16 : size == 4 ? PointField::INT32 : 0;
+    return 0;
+}
+
 bool read_pcd(const std::string& path, PointCloud2* out, std::string* err) {
     std::ifstream f(path, std::ios::binary);
     if (!f) { if (err) *err = "cannot open " + path; return false; }
+    f.seekg(0, std::ios::end);
+    const unsigned long long file_size = static_cast<unsigned long long>(f.tellg());
+    f.seekg(0, std::ios::beg);
     std::vector<std::string> names, sizes, types, counts;
-    size_t width = 0, height = 1, points = 0;
+    unsigned long long width = 0, height = 1, points = 0;
+    bool have_points = false;
     std::string data_kind;
     for (std::string line; std::getline(f, line);) {
         if (!line.empty() && line.back() == '\r') line.pop_back();
@@ -36,44 +49,80 @@ bool read_pcd(const std::string& path, PointCloud2* out, std::string* err) {
         else if (key == "COUNT") counts = t;
         else if (key == "WIDTH" && !t.empty()) width = std::strtoull(t[0].c_str(), nullptr, 10);
         else if (key == "HEIGHT" && !t.empty()) height = std::strtoull(t[0].c_str(), nullptr, 10);
-        else if (key == "POINTS" && !t.empty()) points = std::strtoull(t[0].c_str(), nullptr, 10);
+        else if (key == "POINTS" && !t.empty()) { points = std::strtoull(t[0].c_str(), nullptr, 10); have_points = true; }
         else if (key == "DATA" && !t.empty()) { data_kind = t[0]; break; }
     }
-    if (names.empty() || sizes.size() != names.size() || types.size() != names.size()) {
+    if (names.empty() || sizes.size() != names.size() || types.size() != names.size() ||
+        (!counts.empty() && counts.size() != names.size())) {
         if (err) *err = "malformed PCD header in " + path;
         return false;
     }
-    if (points == 0) points = width * height;
-    PointCloud2 m;
-    uint32_t off = 0;
-    for (size_t k = 0; k < names.size(); ++k) {
-        const uint32_t cnt = counts.size() == names.size() ? static_cast<uint32_t>(std::atoi(counts[k].c_str())) : 1u;
-        if (sizes[k] != "4" || types[k] != "F") {
-            if (err) *err = "only FLOAT32 fields are supported (field " + names[k] + ")";
-            return false;
-        }
-        m.fields.push_back({names[k], off, PointField::FLOAT32, cnt});
-        off += 4 * cnt;
+    if (!have_points) {
+        if (height && width > 0xFFFFFFFFull / height) { if (err) *err = "WIDTH x HEIGHT too large in " + path; return false; }
+        points = width * height;
     }
-    m.point_step = off;
+    if (points > 0xFFFFFFFFull) { if (err) *err = "more than 2^32-1 points in " + path; return false; }
+    // Every field takes SIZE x COUNT bytes of a point, whatever its type: clouds written from a PointCloud2 of
+    // pcl::PointXYZI carry '_' padding fields (SIZE 1 TYPE U COUNT 4 / 12), Velodyne clouds a 'ring' (U2). All of them
+    // are kept in the layout; only x, y, z (and intensity) have to be FLOAT32, which find_xyzi checks.
+    PointCloud2 m;
+    unsigned long long off = 0;
+    for (size_t k = 0; k < names.size(); ++k) {
+        char* end = nullptr;
+        const unsigned long long size = std::strtoull(sizes[k].c_str(), &end, 10);
+        const bool size_ok = end && *end == 0 && (size == 1 || size == 2 || size == 4 || size == 8);
+        unsigned long long cnt = 1;
+        bool cnt_ok = true;
+        if (!counts.empty()) { cnt = std::strtoull(counts[k].c_str(), &end, 10); cnt_ok = end && *end == 0 && counts[k][0] != '-' && cnt >= 1 && cnt <= (1u << 20); }
+        const uint8_t dt = size_ok ? pcd_datatype(types[k], static_cast<unsigned>(size)) : 0;
+        if (!size_ok || !cnt_ok || !dt) { if (err) *err = "bad SIZE/TYPE/COUNT of field " + names[k] + " in " + path; return false; }
+        if (names[k] != "_") m.fields.push_back({names[k], static_cast<uint32_t>(off), dt, static_cast<uint32_t>(cnt)});
+        off += size * cnt;
+        if (off > (1u << 24)) { if (err) *err = "point_step too large in " + path; return false; }
+    }
+    m.point_step = static_cast<uint32_t>(off);
+    const unsigned long long header_end = static_cast<unsigned long long>(f.tellg());
+    const unsigned long long left = file_size > header_end ? file_size - header_end : 0;
+    const unsigned long long bytes = points * off;
+    // the header is not trusted with the allocation: the data must be in the file (ascii: at least "0 " per value)
+    unsigned long long values_per_point = 0;
+    for (size_t k = 0; k < names.size(); ++k) values_per_point += counts.empty() ? 1 : std::strtoull(counts[k].c_str(), nullptr, 10);
+    if ((data_kind == "binary" && bytes > left) || (data_kind == "ascii" && points * values_per_point * 2 > left + 1)) {
+        if (err) *err = "header announces more points than the file holds: " + path;
+        return false;
+    }
     m.height = 1;
     m.width = static_cast<uint32_t>(points);
     m.row_step = m.point_step * m.width;
-    m.data.resize(points * m.point_step);
     m.is_dense = false;                       // PCD files may hold NaN points
     if (data_kind == "binary") {
+        m.data.resize(bytes);
         f.read(reinterpret_cast<char*>(m.data.data()), static_cast<std::streamsize>(m.data.size()));
         if (static_cast<size_t>(f.gcount()) != m.data.size()) { if (err) *err = "short read in " + path; return false; }
     } else if (data_kind == "ascii") {
-        const size_t per = m.point_step / 4;
-        float* dst = reinterpret_cast<float*>(m.data.data());
-        for (size_t i = 0; i < points * per; ++i) {
-            std::string tok;
-            if (!(f >> tok)) { if (err) *err = "short ascii data in " + path; return false; }
-            dst[i] = std::strtof(tok.c_str(), nullptr);
+        m.data.assign(bytes, 0);
+        for (unsigned long long i = 0; i < points; ++i) {
+            uint8_t* row = m.data.data() + i * off;
+            unsigned long long o = 0;
+            for (size_t k = 0; k < names.size(); ++k) {
+                const unsigned size = static_cast<unsigned>(std::strtoull(sizes[k].c_str(), nullptr, 10));
+                const unsigned long long cnt = counts.empty() ? 1 : std::strtoull(counts[k].c_str(), nullptr, 10);
+                for (unsigned long long q = 0; q < cnt; ++q, o += size) {
+                    std::string tok;
+                    if (!(f >> tok)) { if (err) *err = "short ascii data in " + path; return false; }
+                    if (types[k] == "F") {
+                        if (size == 4) { const float v = std::strtof(tok.c_str(), nullptr); std::memcpy(row + o, &v, 4); }
+                        else { const double v = std::strtod(tok.c_str(), nullptr); std::memcpy(row + o, &v, 8); }
+                    } else if (types[k] == "U") {
+                        const unsigned long long v = std::strtoull(tok.c_str(), nullptr, 10); std::memcpy(row + o, &v, size);   // little-endian host
+                    } else {
+                        const long long v = std::strtoll(tok.c_str(), nullptr, 10); std::memcpy(row + o, &v, size);
+                    }
+                }
+            }
         }
     } else {
-        if (err) *err = "unsupported DATA " + data_kind;
+        if (err) *err = "unsupported DATA " + data_kind + " (ascii and binary are read; binary_compressed is not)";
         return false;
     }
     *out = std::move(m);

@@ -1,6 +1,8 @@
 // pcd_io.hpp — PCD v0.7 reader/writer for the replay driver (the reference replays rosbags it does
 // not ship: my_cloud_fusion/launch/bag.launch:7; recorded frames here are .pcd files).
-// Supports FLOAT32 fields, DATA ascii and DATA binary (not binary_compressed).
+// Reads DATA ascii and DATA binary (not binary_compressed) with fields of any PCD type, size and count ('_' padding
+// and e.g. a Velodyne 'ring' are skipped over; x, y, z, intensity must be FLOAT32 to be fused); the header's point
+// count is checked against the file's size before anything is allocated.
 #pragma once
 #include <string>
 

@@ -141,8 +141,17 @@ CM_API int cm_get_sensor_matrix(cm_ctx* ctx, uint32_t sensor, float m[12]);
 /* ---- ingest: replaces the subscriber callbacks' deserialise + transformPointCloud + getROI
  * (:318-337 and siblings); the arithmetic itself runs inside cm_merge_voxelize ---------------- */
 /* Copies a sensor_msgs/PointCloud2 payload (n * point_step bytes, FLOAT32 fields at the given
- * byte offsets) into the sensor's HBM slot. Returns after the caller's buffer may be reused. */
+ * byte offsets) into the sensor's HBM slot. Returns after the caller's buffer may be reused.
+ * Never waits for a merge: every slot has two HBM buffers, the frame enqueued last (and its by-products:
+ * cm_merged_copy, cm_ground_copy) reads one, submits fill the other — the reference's callbacks run
+ * beside its 10 Hz loop on AsyncSpinner(6) (:513, :318-337, :549-584). Callable from one thread per sensor. */
 CM_API int cm_submit_cloud(cm_ctx* ctx, uint32_t sensor, const void* host_data, uint32_t n,
+                    uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z, uint32_t off_i);
+/* The same without waiting for the copy either: the H2D transfer is enqueued on the slot's own stream and
+ * the frame that consumes the cloud waits for it ON THE DEVICE. `host_data` must stay valid and unchanged
+ * until that frame has been enqueued and cm_wait (or cm_sync) has returned; memory from cm_host_alloc makes
+ * the transfer a true DMA that overlaps the previous frame's kernels. */
+CM_API int cm_submit_cloud_async(cm_ctx* ctx, uint32_t sensor, const void* host_data, uint32_t n,
                     uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z, uint32_t off_i);
 /* Zero-copy variant: `dev_data` is already resident in HBM and stays valid until the merge that
  * consumes it has completed. */
@@ -162,6 +171,12 @@ CM_API int cm_wait(cm_ctx* ctx, cm_result* res);
 /* Copies the n_out output points to host memory: point_step_out 16 (x,y,z,intensity) or 32 (the
  * pcl::PointXYZI image pcl::toROSMsg puts on the wire: x,y,z,1.0f,intensity,0,0,0). */
 CM_API int cm_result_copy(cm_ctx* ctx, void* host_dst, uint64_t capacity_points, uint32_t point_step_out);
+/* The same (16-byte records only) without waiting: the copy is enqueued behind the frame on the context's
+ * stream; `host_dst` (cm_host_alloc memory for a true DMA) is complete when cm_sync returns. The next frame
+ * may be enqueued right away (stream order keeps it off the result until the copy has read it). */
+CM_API int cm_result_copy_async(cm_ctx* ctx, void* host_dst, uint64_t capacity_points);
+/* Waits for everything enqueued on the context's stream. */
+CM_API int cm_sync(cm_ctx* ctx);
 /* Device pointer of the compact 16-byte result records (valid until the next merge). */
 CM_API int cm_result_device(cm_ctx* ctx, const void** dev_ptr, uint64_t* n_points);
 /* Occupancy of the last CM_OK frame (needs CM_FLAG_OCCUPANCY): absolute voxel cell (i,j,k) and
@@ -172,6 +187,23 @@ CM_API int cm_result_copy_cells(cm_ctx* ctx, int32_t* ijk_host, uint32_t* counts
 CM_API int cm_merged_copy(cm_ctx* ctx, void* host_dst, uint64_t capacity_points, uint64_t* n_points);
 
 /* ---- diagnostics --------------------------------------------------------------------------- */
+/* Per-frame figures of the last frame that was waited for — what the reference logs per callback
+ * (ROS_INFO of the cloud sizes, :334,:360,:386,:413,:452,:505) plus the bytes that moved. */
+typedef struct cm_frame_stats {
+    uint32_t n_sensors;                    /* sensors fused into the frame, in fuse order */
+    uint32_t _pad;
+    uint32_t sensor[CM_MAX_SENSORS];       /* the caller's sensor number */
+    uint32_t n_in[CM_MAX_SENSORS];         /* points submitted */
+    uint32_t n_kept[CM_MAX_SENSORS];       /* ... that were finite, inside the crop box and passed the pre-stages' masks,
+                                              i.e. entered the voxel grid */
+    uint32_t fresh[CM_MAX_SENSORS];        /* 1: a cloud submitted since the previous frame, 0: a stale one rode along (:141) */
+    uint64_t generation[CM_MAX_SENSORS];   /* which accepted submit of that sensor the frame read (1 = its first; CM_SKIPPED ones
+                                              do not count): a caller that counts its accepted submits knows exactly what was consumed */
+    uint64_t bytes_h2d[CM_MAX_SENSORS];    /* payload bytes copied host -> HBM for this frame (0: device submit or stale) */
+    uint64_t bytes_h2d_total, bytes_d2h_total;   /* d2h: result / merged / ground copies since the frame was enqueued */
+    uint64_t bytes_algorithmic;            /* 16 B x points in + 16 B x voxels out */
+} cm_frame_stats;
+CM_API int cm_get_frame_stats(cm_ctx* ctx, cm_frame_stats* out);
 CM_API int cm_get_stage_times(cm_ctx* ctx, cm_stage_times* out);
 CM_API const char* cm_status_string(int status);
 CM_API const char* cm_last_error(cm_ctx* ctx);

@@ -56,14 +56,14 @@ def test_version_and_status_strings(lib):
 
 def test_struct_layout_matches_header(tmp_path):
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "cloudmerge.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include "cloudmerge.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    "sizeof(cm_limits),sizeof(cm_params),sizeof(cm_result),sizeof(cm_stage_times),"
-                   "sizeof(cm_zone),sizeof(cm_ground_params),sizeof(cm_ground_plane));return 0;}\n")
+                   "sizeof(cm_zone),sizeof(cm_ground_params),sizeof(cm_ground_plane),sizeof(cm_frame_stats));return 0;}\n")
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     sizes = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     assert sizes == [C.sizeof(capi.Limits), C.sizeof(capi.Params), C.sizeof(capi.Result), C.sizeof(capi.StageTimes),
-                     C.sizeof(capi.Zone), C.sizeof(capi.GroundParams), C.sizeof(capi.GroundPlane)]
+                     C.sizeof(capi.Zone), C.sizeof(capi.GroundParams), C.sizeof(capi.GroundPlane), C.sizeof(capi.FrameStats)]
 
 
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")

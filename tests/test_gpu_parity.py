@@ -775,3 +775,93 @@ def test_both_finish_kernels_agree_with_the_oracle(min_pts, sort_path, monkeypat
             assert same_bits(g["out"], xyzi_of(out))
             seen.append(bool(g["res"].path_flags & SPLIT))
     assert seen in ([], [True, False])
+
+
+@pytest.mark.parametrize("latest_wins", [False, True])
+def test_submits_after_a_frame_do_not_touch_its_clouds(latest_wins, sort_path):
+    """ADVICE r1 (high) / VERDICT item 4: every slot has two HBM buffers. While a frame is being computed and afterwards,
+    until the next one is enqueued, subscriber threads may submit larger clouds (which used to re-allocate the very
+    buffer the frame's by-products read): cm_merged_copy, the result and its cells must still be the frame's own."""
+    import threading
+    rng = np.random.default_rng(21)
+    small = [xyzi_cloud(rng.uniform(-8, 8, (6_000, 3)), rng.uniform(0, 9, 6_000)) for _ in range(3)]
+    large = [xyzi_cloud(rng.uniform(-8, 8, (40_000, 3)), rng.uniform(10, 19, 40_000)) for _ in range(3)]
+    for k in range(3):
+        small[k].q_xyzw = large[k].q_xyzw = synth.random_quaternion(np.random.default_rng(30 + k))
+    params = MergeParams(leaf=(0.25,) * 3, min_points_per_voxel=0, crop_min=(-7.0, -7.0, -7.0), crop_max=(7.0, 7.0, 7.0))
+    st, merged, out, rep = oracle.merge_voxelize(small, params, threads=2, stable=True)
+    st2, merged2, out2, rep2 = oracle.merge_voxelize(large, params, threads=2, stable=True)
+    flags = capi.FLAG_OCCUPANCY | (capi.FLAG_LATEST_WINS if latest_wins else 0)
+    with capi.CloudMerger(max_points_total=130_000, max_sensors=3, flags=flags) as cm:
+        for rounds in range(3):
+            cm.submit_all(small)
+            cp = capi.make_params(params)
+            assert cm.merge_voxelize_async(cp) == capi.OK
+            errs = []
+
+            def late(k):
+                try:
+                    for _ in range(1 + 2 * int(latest_wins)):
+                        cm.submit(k, large[k])       # larger than anything the slot held: a fresh allocation
+                except Exception as e:               # pragma: no cover
+                    errs.append(e)
+            ts = [threading.Thread(target=late, args=(k,)) for k in range(3)]
+            for t in ts:
+                t.start()                            # (while the frame is in flight ...)
+            res = cm.wait()
+            for t in ts:
+                t.join()                             # (... and certainly done before the by-products are read)
+            assert not errs, errs
+            assert res.status == st == capi.OK and res.n_in == rep.n_in and res.n_out == rep.n_out
+            got_merged = xyzi4(cm.merged(130_000))
+            assert same_bits(got_merged, xyzi_of(merged)), "cm_merged_copy must read the frame's own clouds"
+            cells, counts = cm.cells(res.n_out)
+            assert np.array_equal(cells, rep.cells) and np.array_equal(counts, rep.counts)
+            # the clouds submitted meanwhile make the next frame, whole
+            res2 = cm.merge_voxelize(params)
+            assert res2.status == capi.OK and res2.n_in == rep2.n_in and res2.n_out == rep2.n_out
+            assert same_bits(xyzi4(cm.merged(130_000)), xyzi_of(merged2))
+
+
+def test_async_submit_result_and_frame_stats(sort_path):
+    """cm_submit_cloud_async (no host wait for the H2D copy: the frame waits for it on the device), cm_result_copy_async +
+    cm_sync, and cm_get_frame_stats: points in / kept per sensor, bytes moved."""
+    sensors, params = synth.config3(n_per_sensor=60_000, n_sensors=4, min_pts=2, leaf=0.1)
+    st, merged, out, rep = oracle.merge_voxelize(sensors, params, threads=4, stable=True)
+    holders, ptrs = [], []
+    for s in sensors:
+        raw = np.ascontiguousarray(s.data).view(np.uint8).reshape(-1)
+        h = capi.pinned_array(raw.nbytes)
+        h.array[:] = raw
+        holders.append(h)
+        ptrs.append(h.ptr.value)
+    dst = capi.pinned_array(16 * 240_000)
+    try:
+        with capi.CloudMerger(max_points_total=240_000, max_sensors=4, flags=capi.FLAG_OCCUPANCY) as cm:
+            for frame in range(3):
+                for k, s in enumerate(sensors):
+                    cm.set_transform(k, s.q_xyzw, s.t_xyz)
+                    assert cm.submit_async(k, s, host_ptr=ptrs[k]) == capi.OK
+                assert cm.merge_voxelize_async(capi.make_params(params)) == capi.OK
+                res = cm.wait()
+                assert res.status == st == capi.OK and res.n_out == rep.n_out
+                cm.result_async(dst.ptr.value, 240_000)
+                cm.sync()
+                got = np.frombuffer(dst.array[: 16 * res.n_out].tobytes(), dtype=np.float32).reshape(-1, 4)
+                assert_centroids_close(got, xyzi_of(out))
+                cells, counts = cm.cells(res.n_out)
+                assert np.array_equal(cells, rep.cells) and np.array_equal(counts, rep.counts)
+                fs = cm.frame_stats()
+                assert fs["sensor"] == [0, 1, 2, 3] and fs["n_in"] == [s.n for s in sensors] and fs["fresh"] == [1] * 4
+                assert fs["bytes_h2d"] == [s.n * s.point_step for s in sensors]
+                assert fs["bytes_h2d_total"] == sum(fs["bytes_h2d"]) and fs["bytes_d2h_total"] == 16 * res.n_out
+                assert fs["bytes_algorithmic"] == 16 * res.n_in + 16 * res.n_out
+                # points per sensor that survive the crop: the oracle's merged cloud is in sensor order
+                kept = []
+                for s in sensors:
+                    _, m1, _, r1 = oracle.merge_voxelize([s], params, threads=1, stable=True)
+                    kept.append(int(r1.n_merged))
+                assert fs["n_kept"] == kept and sum(kept) == rep.n_merged
+    finally:
+        for h in holders + [dst]:
+            h.free()
