@@ -75,6 +75,7 @@ struct cm_ctx {
     bool lds_rank = false;               // k_probe_lds_order found lane-ordered LDS adds on this device
     int finish_mode = 0;                 // CM_FINISH: 0 k3_local + k3_compact, 2 (CM_FINISH=v2) k2_local with its look-back
     void* stage32 = nullptr;             // k3_local's staging for partial tables (32-byte entries)
+    void* out32 = nullptr;               // the result as pcl::PointXYZI images (cm_result_copy with point_step_out 32)
     int debug_misrank = 0;               // CM_DEBUG_MISRANK=1 (tests): the last global pass swaps two records of tile 0
     float* partials = nullptr;
     uint32_t *out_key = nullptr, *out_cnt = nullptr, *merged_total = nullptr;
@@ -263,7 +264,7 @@ void free_all(cm_ctx* c) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(c->keys_a); F(c->keys_b); F(c->vals_a); F(c->vals_b); F(c->hist); F(c->totals);
     F(c->seg_counts); F(c->seg_tile_counts); F(c->seg_groups); F(c->grp); F(c->partials); F(c->out_key); F(c->out_cnt); F(c->merged_total); F(c->out); F(c->merged); F(c->partial); F(c->table_entries); F(c->mask); F(c->sorted_pts); F(c->rows); F(c->d_state_o);
-    F(c->stage32); F(c->rec_a); F(c->rec_b); F(c->dig); F(c->tile_state); F(c->wave_cnt); F(c->records);
+    F(c->stage32); F(c->out32); F(c->rec_a); F(c->rec_b); F(c->dig); F(c->tile_state); F(c->wave_cnt); F(c->records);
     F(c->d_ground); F(c->d_state_g); F(c->gmask); F(c->zone_off); F(c->d_planes); F(c->hyp0); F(c->valid0); F(c->counts0); F(c->chunk_sums); F(c->bmask); F(c->zcode);
     F(c->d_frame); F(c->d_tiles); F(c->d_state[0]); F(c->d_state[1]);
     if (c->h_state) (void)hipHostFree(c->h_state);
@@ -1266,15 +1267,12 @@ int cm_result_copy(cm_ctx* c, void* host_dst, uint64_t capacity_points, uint32_t
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         return CM_OK;
     }
-    std::vector<float> tmp(n * 4);
-    HIP_TRY(c, hipMemcpyAsync(tmp.data(), c->out, n * 16, hipMemcpyDeviceToHost, c->stream));
+    // pcl::PointXYZI images (A.0) are laid out on the device and cross PCIe as they go on the wire
+    if (!c->out32) HIP_TRY(c, hipMalloc(&c->out32, static_cast<size_t>(c->cap_padded) * 32));
+    cmk_to_pcl32(c->stream, c->out, c->out32, static_cast<uint32_t>(n));
+    HIP_TRY(c, hipMemcpyAsync(host_dst, c->out32, n * 32, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    float* d = static_cast<float*>(host_dst);     // pcl::PointXYZI image (A.0)
-    for (uint64_t i = 0; i < n; ++i) {
-        d[8 * i + 0] = tmp[4 * i + 0]; d[8 * i + 1] = tmp[4 * i + 1]; d[8 * i + 2] = tmp[4 * i + 2];
-        d[8 * i + 3] = 1.0f; d[8 * i + 4] = tmp[4 * i + 3];
-        d[8 * i + 5] = d[8 * i + 6] = d[8 * i + 7] = 0.0f;
-    }
+    c->bytes_d2h += n * 16;
     return CM_OK;
 }
 

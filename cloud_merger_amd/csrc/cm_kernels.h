@@ -40,6 +40,7 @@ void cmk_table_keys(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint3
                     uint32_t n_tiles);
 void cmk_table_finish(hipStream_t s, const void* entries, uint32_t n, uint32_t min_pts, uint32_t* tile_counts,
                       uint32_t* total, void* out, uint32_t* out_key, uint32_t* out_cnt);
+void cmk_to_pcl32(hipStream_t s, const void* in, void* out, uint32_t n);      // 16-byte records -> pcl::PointXYZI images
 void cmk_merged(hipStream_t s, const CmFrameDev* fd, uint32_t* tile_counts, uint32_t* total, void* out,
                 uint32_t n_tiles, const unsigned char* mask);
 

@@ -1266,6 +1266,16 @@ __global__ __launch_bounds__(CM_BLOCK) void k_merged_write(const CmFrameDev* __r
     }
 }
 
+// The image pcl::toROSMsg puts on the wire for pcl::PointXYZI: x, y, z, 1.0f | intensity, 0, 0, 0.
+__global__ __launch_bounds__(256) void k_to_pcl32(const float4* __restrict__ in, float4* __restrict__ out, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const float4 v = in[i];
+        out[2 * static_cast<size_t>(i)] = make_float4(v.x, v.y, v.z, 1.0f);
+        out[2 * static_cast<size_t>(i) + 1] = make_float4(v.w, 0.f, 0.f, 0.f);
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -1381,4 +1391,7 @@ void cmk_merged(hipStream_t s, const CmFrameDev* fd, uint32_t* tile_counts, uint
     CM_LAUNCH(k_merged_count, n_tiles, CM_BLOCK, s, fd, tile_counts, mask);
     CM_LAUNCH(k_scan_counts, 1, CM_BLOCK, s, tile_counts, n_tiles, total);
     CM_LAUNCH(k_merged_write, n_tiles, CM_BLOCK, s, fd, tile_counts, reinterpret_cast<float4*>(out), mask);
+}
+void cmk_to_pcl32(hipStream_t s, const void* in, void* out, uint32_t n) {
+    if (n) CM_LAUNCH(k_to_pcl32, (n + 255) / 256, 256, s, reinterpret_cast<const float4*>(in), reinterpret_cast<float4*>(out), n);
 }

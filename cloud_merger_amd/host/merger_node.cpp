@@ -204,7 +204,8 @@ bool CloudMergerNode::transforms_ready() const {
     return true;
 }
 
-int CloudMergerNode::on_cloud(size_t sensor, const PointCloud2& msg) {
+int CloudMergerNode::on_cloud(size_t sensor, const PointCloud2& msg, bool* accepted) {
+    if (accepted) *accepted = false;
     if (!ctx_ || sensor >= cfg_.sensors.size()) return CM_BAD_ARG;
     if (!transforms_ready()) return CM_NOT_READY;
     const XyziLayout l = find_xyzi(msg);
@@ -212,6 +213,7 @@ int CloudMergerNode::on_cloud(size_t sensor, const PointCloud2& msg) {
     const int st = cm_submit_cloud(ctx_, static_cast<uint32_t>(sensor), msg.data.data(),
                                    static_cast<uint32_t>(msg.num_points()), msg.point_step, l.off_x, l.off_y, l.off_z, l.off_i);
     if (st == CM_OK) { stamp_ns_[sensor].store(msg.header.stamp_ns); submitted_[sensor].fetch_add(1); }   // CM_SKIPPED: the slot keeps its older cloud
+    if (accepted) *accepted = st == CM_OK;
     return st == CM_SKIPPED ? CM_OK : st;
 }
 
@@ -251,7 +253,14 @@ int CloudMergerNode::spin_once(cm_result* res) {
                 if (fs.sensor[k] < consumed_.size()) consumed_[fs.sensor[k]].store(fs.generation[k]);
     }
     // publishPointcloud, voxel leg (:215-219): PCL layout, stamp = now, frame = base_footprint.
-    PointCloud2 msg = cfg_.publish_pcl_layout ? make_pcl_xyzi_message(r.n_out) : make_xyzi16_message(r.n_out);
+    PointCloud2& msg = out_msg_;
+    {
+        const bool pcl = cfg_.publish_pcl_layout;
+        if (msg.fields.empty() || msg.point_step != (pcl ? 32u : 16u)) msg = pcl ? make_pcl_xyzi_message(0) : make_xyzi16_message(0);
+        msg.height = 1; msg.width = static_cast<uint32_t>(r.n_out);
+        msg.row_step = msg.point_step * msg.width;
+        msg.data.resize(static_cast<size_t>(r.n_out) * msg.point_step);    // (capacity is kept: no zero-fill in steady state)
+    }
     if (st == CM_EMPTY_INPUT) { msg.width = 0; msg.height = 0; msg.row_step = 0; }   // A.4 step 1
     if (r.n_out) {
         const int cs = cm_result_copy(ctx_, msg.data.data(), r.n_out, msg.point_step);
@@ -266,7 +275,9 @@ int CloudMergerNode::spin_once(cm_result* res) {
         // publishPointcloud's other two legs (:203-213): the fused no-ground and ground clouds
         for (int leg = 0; leg < 2; ++leg) {
             uint64_t n = 0;
-            PointCloud2 m2 = make_xyzi16_message(static_cast<size_t>(r.n_in));
+            PointCloud2& m2 = side_msg_;
+            if (m2.fields.empty()) m2 = make_xyzi16_message(0);
+            m2.data.resize(static_cast<size_t>(r.n_in) * m2.point_step);
             const int cs = leg == 0 ? cm_merged_copy(ctx_, m2.data.data(), r.n_in, &n) : cm_ground_copy(ctx_, m2.data.data(), r.n_in, &n);
             if (cs != CM_OK) { set_error(cm_last_error(ctx_)); return cs; }
             m2.width = static_cast<uint32_t>(n); m2.height = n ? 1 : 0; m2.row_step = static_cast<uint32_t>(n) * m2.point_step;

@@ -99,7 +99,9 @@ public:
     // sensors (AsyncSpinner(6), :513). Returns a cm_status; clouds are ignored until every
     // transform is known, like the reference, whose callbacks run on default transforms before
     // flag_tf but whose fuse gate only opens afterwards.
-    int on_cloud(size_t sensor, const PointCloud2& msg);
+    // *accepted (optional): false when the slot still held an unconsumed cloud and this one was dropped (:330) — the
+    // call still returns CM_OK like the reference's callback; a lossless replay waits and offers the cloud again.
+    int on_cloud(size_t sensor, const PointCloud2& msg, bool* accepted = nullptr);
 
     void set_publisher(Publisher p) { publish_ = std::move(p); }
     void set_clock(Clock c) { clock_ = std::move(c); }
@@ -124,6 +126,7 @@ private:
     void set_error(const std::string& e) { std::lock_guard<std::mutex> lk(err_mu_); error_ = e; }
     std::atomic<uint64_t> frames_{0};
     uint32_t seq_ = 0;
+    PointCloud2 out_msg_, side_msg_;               // reused from frame to frame (no 3 MB zero-fill per publish)
     std::vector<std::atomic<uint64_t>> stamp_ns_;   // stamp of the cloud each sensor slot currently holds
     // A slot holds a cloud no fuse has consumed yet when more submits were accepted for it than the last fuse had seen
     // (cm_frame_stats.generation): exact, whichever way a callback and the fuse interleave.

@@ -6,9 +6,15 @@
 //   cloudmerge_replay --dir SEQ --sensors 4 --frames 100 [--config NODE.cfg] [--leaf 0.05] [--min-pts 2]
 //                     [--crop x0 y0 z0 x1 y1 z1] [--outlier RADIUS MIN_NEIGHBOURS] [--out OUTDIR]
 //                     [--device 0] [--shard 0/1]
-//                     [--rate 10 --realtime]
+//                     [--rate 10 --realtime] [--threads]
+// --threads: the reference's threading — one subscriber thread per sensor (ros::AsyncSpinner(6), :513) hands the clouds to
+//   the node while the main thread runs the loop body (:570-580). A sensor's thread offers its next cloud again until the
+//   slot has been consumed (lossless, unlike the live node, which drops: :330), so frame k is made of every sensor's
+//   cloud k. The copy of frame k+1 into HBM then runs beside frame k's kernels and its publish: the slots are double-buffered.
 // SEQ/transforms.txt : one line per sensor "qx qy qz qw tx ty tz" (tf lookup results)
 // SEQ/frame_%04d_sensor_%d.pcd : FIELDS x y z [intensity], FLOAT32
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -26,7 +32,8 @@ int main(int argc, char** argv) {
     std::string dir, out_dir;
     int n_sensors = 4, n_frames = 1, device = 0, rank = 0, world = 1;
     double rate = 10.0;
-    bool realtime = false, have_config = false;
+    bool realtime = false, have_config = false, threads = false;
+    int repeat = 1;
     NodeConfig cfg;
     cfg.params.leaf[0] = cfg.params.leaf[1] = cfg.params.leaf[2] = 0.05f;
     cfg.params.min_points_per_voxel = 2;
@@ -46,6 +53,8 @@ int main(int argc, char** argv) {
         else if (k == "--device") device = std::atoi(next());
         else if (k == "--rate") rate = std::atof(next());
         else if (k == "--realtime") realtime = true;
+        else if (k == "--threads") threads = true;
+        else if (k == "--repeat") repeat = std::max(1, std::atoi(next()));      // --threads: play the sequence this many times (the first pass is the warm-up: not timed)
         else if (k == "--leaf") { const float v = std::strtof(next(), nullptr); cfg.params.leaf[0] = cfg.params.leaf[1] = cfg.params.leaf[2] = v; }
         else if (k == "--min-pts") cfg.params.min_points_per_voxel = static_cast<uint32_t>(std::atoi(next()));
         else if (k == "--crop") {
@@ -105,6 +114,58 @@ int main(int argc, char** argv) {
             if (!write_pcd(out_dir + buf, msg, &e)) std::fprintf(stderr, "%s\n", e.c_str());
         }
     });
+
+    if (threads) {
+        // everything is read before the clock starts (rosbag play delivers messages, it does not parse files in the callback)
+        std::vector<int> my_frames;
+        for (int f = rank; f < n_frames; f += world) my_frames.push_back(f);
+        std::vector<std::vector<PointCloud2>> all(my_frames.size(), std::vector<PointCloud2>(n_sensors));
+        for (size_t i = 0; i < my_frames.size(); ++i)
+            for (int s = 0; s < n_sensors; ++s) {
+                if (!read_pcd(frame_path(my_frames[i], s), &all[i][s], &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
+                points += all[i][s].num_points();
+            }
+        std::atomic<bool> failed{false};
+        const size_t n_play = all.size() * static_cast<size_t>(repeat);
+        const size_t n_warm = repeat > 1 ? all.size() : 0;
+        auto t0 = std::chrono::steady_clock::now();
+        std::vector<std::thread> subs;
+        for (int s = 0; s < n_sensors; ++s)
+            subs.emplace_back([&, s] {
+                for (size_t j = 0; j < n_play && !failed.load(); ++j) {
+                    const size_t i = j % all.size();
+                    bool accepted = false;
+                    while (!accepted && !failed.load()) {
+                        const int st = node.on_cloud(static_cast<size_t>(s), all[i][s], &accepted);
+                        if (st != CM_OK) { std::fprintf(stderr, "on_cloud: %s (%s)\n", cm_status_string(st), node.error().c_str()); failed.store(true); }
+                        if (!accepted) std::this_thread::yield();
+                    }
+                }
+            });
+        int done = 0;
+        uint64_t voxels_warm = 0;
+        while (done < static_cast<int>(n_play) && !failed.load()) {
+            if (static_cast<size_t>(done) == n_warm && n_warm) { t0 = std::chrono::steady_clock::now(); voxels_warm = voxels; }
+            cur_frame = my_frames[static_cast<size_t>(done) % all.size()];
+            cm_result r{};
+            const int st = node.spin_once(&r);
+            if (st == CM_NOT_READY) { std::this_thread::yield(); continue; }
+            if (st < 0) { std::fprintf(stderr, "frame %d: %s\n", cur_frame, cm_status_string(st)); failed.store(true); break; }
+            ++done;
+            if (realtime) std::this_thread::sleep_until(t0 + std::chrono::duration<double>(done / rate));
+        }
+        for (auto& t : subs) t.join();
+        if (failed.load()) return 1;
+        const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const int timed = done - static_cast<int>(n_warm);
+        const uint64_t pts_timed = points * static_cast<uint64_t>(repeat > 1 ? repeat - 1 : 1);
+        std::printf("{\"rank\": %d, \"world\": %d, \"frames\": %d, \"points_in\": %llu, \"voxels_out\": %llu, "
+                    "\"wall_s\": %.6f, \"submit_merge_publish_s\": %.6f, \"frames_per_s\": %.2f, \"points_per_s\": %.3e, "
+                    "\"mode\": \"subscriber threads (%d) + loop thread\", \"warmup_frames\": %d}\n",
+                    rank, world, timed, static_cast<unsigned long long>(pts_timed), static_cast<unsigned long long>(voxels - voxels_warm),
+                    wall, wall, timed / wall, pts_timed / wall, n_sensors, static_cast<int>(n_warm));
+        return 0;
+    }
 
     const auto t0 = std::chrono::steady_clock::now();
     double t_gpu = 0;

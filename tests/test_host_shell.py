@@ -47,7 +47,8 @@ def test_host_unit_tests_gpu(host_bins, tmp_path):
 
 
 @pytest.mark.gpu
-def test_replay_sequence_matches_oracle(host_bins, tmp_path):
+@pytest.mark.parametrize("threads", [False, True])
+def test_replay_sequence_matches_oracle(host_bins, tmp_path, threads):
     from oracle import oracle
     from tests.util import assert_centroids_close, xyzi_of
 
@@ -57,7 +58,8 @@ def test_replay_sequence_matches_oracle(host_bins, tmp_path):
     poses = replay_data.write_sequence(seq, frames=frames, sensors=sensors, rings=16, azimuths=900)
     crop = ["-15", "-5", "-0.5", "60", "5", "3"]
     r = subprocess.run([os.path.join(host_bins, "cloudmerge_replay"), "--dir", seq, "--sensors", str(sensors),
-                        "--frames", str(frames), "--leaf", "0.1", "--min-pts", "2", "--crop", *crop, "--out", out],
+                        "--frames", str(frames), "--leaf", "0.1", "--min-pts", "2", "--crop", *crop, "--out", out]
+                       + (["--threads"] if threads else []),      # subscriber threads beside the loop thread (AsyncSpinner(6), :513)
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     stats = json.loads(r.stdout.strip().splitlines()[-1])
