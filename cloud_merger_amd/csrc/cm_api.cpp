@@ -489,6 +489,10 @@ int bucket_buffers(cm_ctx* c) {
 // left to the local finish, and enough that an average bucket (points / 2^(8 g)) stays well inside its LDS
 // capacity. 0: the bucket kernels do not fit this grid.
 uint32_t bucket_passes(uint32_t kb, uint64_t est, uint32_t extra) {
+    // Dense frames — on average a point or more per cell of the box (the reference's own 10 cm grid on its ROI, or any
+    // coarse leaf): sort the whole index globally. The finish then has nothing left to sort, a "bucket" is one voxel, and
+    // a voxel of any size is summed by the long-run jobs of k3_local: no bucket can be too large, nothing is handed back.
+    if (kb <= 8 * CM_MAX_PASSES && (est >> kb) >= 1) return (kb + 7) / 8;
     uint32_t g = 1 + (kb > CM2_MAX_LOW_BITS + 8 ? (kb - CM2_MAX_LOW_BITS - 1) / 8 : 0);
     while (g < CM_MAX_PASSES && (est >> (8 * g)) > 256) ++g;
     g += extra;

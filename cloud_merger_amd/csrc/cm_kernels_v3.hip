@@ -58,6 +58,23 @@ __device__ __forceinline__ float div_by_count3(float x, float c, float rc) {   /
     return finite_f32(q) ? q2 : q;
 }
 
+// Sum of a float over the wave in a fixed order (the DPP ladder of wave_incl_scan_u32: rows of 16, then across rows),
+// the same in every lane. Deterministic; NOT the sequential order — used for long runs only (see the long-run jobs).
+__device__ __forceinline__ float wave_sum_f32_fixed(float v) {
+#define CM3_FADD(ctrl, rmask) v = __fadd_rn(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xf, false)))
+    CM3_FADD(0x111, 0xf); CM3_FADD(0x112, 0xf); CM3_FADD(0x114, 0xf); CM3_FADD(0x118, 0xf);
+    CM3_FADD(0x142, 0xa); CM3_FADD(0x143, 0xc);
+#undef CM3_FADD
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+struct Job3 {                      // a voxel that runs far past its owner's block: finished by a whole wave
+    uint32_t p, key, kid, cnt;     // next sorted position, the voxel's key, its number among the tile's kept voxels, points so far
+    float sx, sy, sz, sw;          // sums so far
+};
+#define CM3_EXT_SEQ 16u            // positions past its block a thread still adds one after the other
+#define CM3_RUN_MAX (1u << 20)     // a voxel with more points than this goes back to the general path (parallel tree sums)
+
 template <int WAVES>
 __device__ __forceinline__ uint32_t block_excl_scan3(uint32_t v, uint32_t* lds, uint32_t* total) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -109,7 +126,8 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
     __shared__ uint16_t si[LCAP];                      // slots in sorted order
     __shared__ uint32_t whist[LWAVES][HWORDS];         // digit counts per wave
     __shared__ uint32_t lds[2 * LWAVES];
-    __shared__ uint32_t s_a, s_keyprev, s_bad;
+    __shared__ uint32_t s_a, s_keyprev, s_bad, s_njobs;
+    Job3* jobs = reinterpret_cast<Job3*>(&whist[0][0]);         // (the counters are dead once the sort is over: 512 jobs fit)
 
     PH3_START();
     // (values that are the same in every lane are put into scalar registers by hand — the compiler cannot tell for what
@@ -147,7 +165,7 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
             if (q < nom) sk[q] = key3(b, r4[r]);
         }
         if (has_e) sk[LT + threadIdx.x] = key3(b, e4);
-        if (threadIdx.x == 0) { s_keyprev = base > 0 ? key3(b, pv) : 0u; s_a = 0xFFFFFFFFu; s_bad = 0u; }
+        if (threadIdx.x == 0) { s_keyprev = base > 0 ? key3(b, pv) : 0u; s_a = 0xFFFFFFFFu; s_bad = 0u; s_njobs = 0u; }
     }
     __syncthreads();
     PH3(0);
@@ -175,7 +193,10 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
     bad_order = bad_order || (in_e && (sk[LT + threadIdx.x] >> L) < h_last);
     uint32_t ext = SCAL(__syncthreads_count(m0));         // also orders the atomicMin above
     const uint32_t a = SCAL(s_a);
-    bool too_big = false;
+    // With no bits left to sort (L == 0: a bucket is ONE voxel, its records already in their final order) a voxel need not
+    // fit: what LDS cannot hold is read straight from HBM when its sum is finished ("open tail", the long-run jobs below).
+    const bool may_open = L == 0 && (min_pts - 1u) < static_cast<uint32_t>(LCAP - LT);
+    bool too_big = false, tail_open = false;
     if (ext == EXT0 && a != 0xFFFFFFFFu) {
         for (uint32_t off = EXT0;; off += LBLOCK) {
             const uint32_t j = base + LT + off + threadIdx.x;
@@ -190,7 +211,10 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
             }
             const uint32_t c = SCAL(__syncthreads_count(mm));
             ext += c;
-            if (LT + ext > LCAP) { too_big = true; break; }
+            if (LT + ext > LCAP) {
+                if (may_open) { tail_open = true; ext = LCAP - LT; } else too_big = true;
+                break;
+            }
             if (c < LBLOCK) break;
         }
     }
@@ -201,7 +225,11 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
     PH3(1);
     // ---- sort the owned slots [a, a+m) by key: LSD over the bits in which the keys of this tile can differ, up to
     // 10 per pass, stable; only the slot numbers move. Ranking: returning LDS adds on per-wave counters.
-    if (m) {
+    if (m && L == 0) {                                         // already in key order: the sorted position IS the slot
+        for (uint32_t e = threadIdx.x; e < m; e += LBLOCK) si[e] = static_cast<uint16_t>(a + e);
+        __syncthreads();
+    }
+    if (m && L != 0) {
         const uint32_t h_first = SCAL(sk[a] >> L);
         const uint32_t kbase = h_first << L;
         const unsigned long long span = static_cast<unsigned long long>(h_last - h_first + 1u) << L;
@@ -341,12 +369,10 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
             if (PARTIAL) {                                     // cm_partial_entry: key, count, sx, sy | sz, si, 0, 0
                 stage[2 * o] = make_float4(__uint_as_float(key), __uint_as_float(cn), sx, sy);
                 stage[2 * o + 1] = make_float4(sz, sw, 0.f, 0.f);
-            } else {
-                const float c = static_cast<float>(cn);
-                const float rc = __frcp_rn(c);                  // RN(1/c), shared by the four quotients
-                stage[o] = make_float4(div_by_count3(sx, c, rc), div_by_count3(sy, c, rc), div_by_count3(sz, c, rc),
-                                       div_by_count3(sw, c, rc));
-                if (stage_key) { stage_key[o] = key; stage_cnt[o] = cn; }
+            } else {                                           // sums and count; k3_compact divides while it packs
+                stage[o] = make_float4(sx, sy, sz, sw);
+                stage_cnt[o] = cn;
+                if (stage_key) stage_key[o] = key;
             }
         };
         uint32_t kid = kid0, cn = 0, ckey = 0;
@@ -358,7 +384,7 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
             if ((heads >> j) & 1u) {
                 if (on) emit(kid++, ckey, sx, sy, sz, sw, cn);
                 on = (kheads >> j) & 1u;
-                sx = sy = sz = sw = 0.f; cn = 0; ckey = k[j];
+                sx = sy = sz = sw = 0.f; cn = 0; ckey = sk[sl[j]];       // (read again: keeping the eight keys alive costs registers)
             }
             if ((ldm >> j) & 1u) {
                 sx = __fadd_rn(sx, r4[j].x); sy = __fadd_rn(sy, r4[j].y); sz = __fadd_rn(sz, r4[j].z); sw = __fadd_rn(sw, r4[j].w);
@@ -366,10 +392,12 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
             }
         }
         if (on) {
-            // the last voxel may go on past the block: four positions at a time, loads first
+            // the last voxel may go on past the block: four positions at a time, loads first — up to CM3_EXT_SEQ positions
+            // one after the other (stable order, bit for bit pcl's sum); a voxel longer than that is finished by a wave
             uint32_t p = i0 + per;
-            bool more = p < m;
-            while (more) {
+            bool more = p < m || (tail_open && p == m);
+            uint32_t steps = 0;
+            while (more && p < m && steps < CM3_EXT_SEQ / 4u) {
                 uint16_t s4[4];
                 float4 e4[4];
                 uint32_t nmatch = 0;
@@ -391,10 +419,65 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
                         ++cn;
                     }
                 }
-                p += 4;
-                more = nmatch == 4 && p < m;
+                p += nmatch;
+                more = nmatch == 4 && (p < m || tail_open);
+                ++steps;
             }
-            emit(kid++, ckey, sx, sy, sz, sw, cn);
+            if (more) {                                        // (p < m, or p == m with the tail open)
+                const uint32_t jn = atomicAdd(&s_njobs, 1u);
+                Job3 jb;
+                jb.p = p; jb.key = ckey; jb.kid = kid++; jb.cnt = cn; jb.sx = sx; jb.sy = sy; jb.sz = sz; jb.sw = sw;
+                jobs[jn] = jb;
+            } else {
+                emit(kid++, ckey, sx, sy, sz, sw, cn);
+            }
+        }
+
+        // ---- long voxels: wave w takes jobs w, w + LWAVES, ... 64 positions per step, every record of a step fetched at
+        // once, the step's sum formed in a fixed tree order and added to the running sum step after step: deterministic,
+        // within 1e-4 m of pcl's one-after-the-other sum (closer to the exact mean, in fact), not bit-identical to it.
+        __syncthreads();
+        const uint32_t njobs = SCAL(s_njobs);
+        for (uint32_t jn = w; jn < njobs; jn += LWAVES) {
+            const Job3 jb = jobs[jn];
+            uint32_t p = SCAL(jb.p), cnj = SCAL(jb.cnt);
+            const uint32_t jkey = SCAL(jb.key);
+            float ax = jb.sx, ay = jb.sy, az = jb.sz, aw = jb.sw;
+            bool ended = false;
+            while (!ended) {
+                // eight chunks of 64 positions per step: all their records asked for at once, then chunk after chunk
+                // reduced in a fixed tree order and added to the running sum
+                constexpr int JU = 8;
+                float4 r4[JU];
+                bool in[JU];
+#pragma unroll
+                for (int u = 0; u < JU; ++u) {
+                    const uint32_t q = p + u * 64 + lane;
+                    in[u] = false;
+                    r4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (L == 0) {                              // sorted position q is record base + a + q, in LDS or not
+                        const unsigned long long idx = static_cast<unsigned long long>(base) + a + q;
+                        if (idx < n) { r4[u] = rec[idx]; in[u] = true; }
+                    } else if (q < m) {
+                        const uint32_t sl_ = si[q];
+                        if (sk[sl_] == jkey) { r4[u] = rec[base + sl_]; in[u] = true; }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < JU; ++u) {
+                    if (ended) break;                          // (uniform)
+                    if (L == 0) in[u] = in[u] && key3(b, r4[u]) == jkey;
+                    const unsigned long long bal = __ballot(in[u]);
+                    if (!in[u]) r4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    ax = __fadd_rn(ax, wave_sum_f32_fixed(r4[u].x)); ay = __fadd_rn(ay, wave_sum_f32_fixed(r4[u].y));
+                    az = __fadd_rn(az, wave_sum_f32_fixed(r4[u].z)); aw = __fadd_rn(aw, wave_sum_f32_fixed(r4[u].w));
+                    cnj += static_cast<uint32_t>(__popcll(bal));
+                    ended = bal != ~0ull;                      // the run ended inside this chunk
+                }
+                p += 64 * JU;
+                if (cnj > CM3_RUN_MAX) { if (lane == 0) host_state[offsetof(CmFrameState, err) / 4] = CM_DEV_ERR_BUCKET; break; }
+            }
+            if (lane == 0) emit(SCAL(jb.kid), jkey, ax, ay, az, aw, cnj);
         }
     }
     PH3(3);
@@ -447,8 +530,13 @@ __global__ __launch_bounds__(256) void k3_compact(const CmFrameState* __restrict
             out[2 * (static_cast<size_t>(prefix) + q)] = stage[2 * (src + q)];
             out[2 * (static_cast<size_t>(prefix) + q) + 1] = stage[2 * (src + q) + 1];
         } else {
-            out[prefix + q] = stage[src + q];
-            if (out_key) { out_key[prefix + q] = stage_key[src + q]; out_cnt[prefix + q] = stage_cnt[src + q]; }
+            const float4 sm = stage[src + q];
+            const uint32_t cn = stage_cnt[src + q];
+            const float c = static_cast<float>(cn);
+            const float rc = __frcp_rn(c);                      // RN(1/c), shared by the four quotients
+            out[prefix + q] = make_float4(div_by_count3(sm.x, c, rc), div_by_count3(sm.y, c, rc), div_by_count3(sm.z, c, rc),
+                                          div_by_count3(sm.w, c, rc));
+            if (out_key) { out_key[prefix + q] = stage_key[src + q]; out_cnt[prefix + q] = cn; }
         }
     }
 }

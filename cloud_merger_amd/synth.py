@@ -84,6 +84,61 @@ def config2(n_per_sensor=1_000_000, n_sensors=4, min_pts=0, layout="xyzi16"):
     return sensors, MergeParams(leaf=(0.05,) * 3, min_points_per_voxel=min_pts)
 
 
+def config2_stream(frame, n_per_sensor=1_000_000, n_sensors=4, min_pts=0, wide=False):
+    """Frame `frame` of a moving cfg2 stream: the same four sensors (poses of config2, jittered by a few centimetres and
+    a fraction of a degree from frame to frame, as a vehicle's vibration does), a fresh draw of the same scene
+    statistics every frame. wide=True: the cloud reaches 30 % further out — a frame that leaves the box predicted
+    from its predecessors (bench.py inserts one now and then)."""
+    sensors = []
+    for s in range(n_sensors):
+        rng = _rng(2001 + s)
+        q = random_quaternion(rng)
+        t = rng.uniform(-2, 2, 3)
+        rf = _rng(2001 + s + 1000 * (frame + 1))
+        dq = np.concatenate([rf.normal(0, 2e-3, 3), [1.0]])           # a small rotation, composed on the right
+        x1, y1, z1, w1 = q
+        x2, y2, z2, w2 = dq / np.linalg.norm(dq)
+        qj = np.array([w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+                       w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2, w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2])
+        tj = t + rf.normal(0, 0.02, 3)
+        xyz, inten = ground_scene(rf, n_per_sensor, 14.0, -2.0, 4.0)
+        if wide:
+            xyz = (xyz * np.float32(1.3)).astype(np.float32)
+        data, lay = pack(xyz, inten, "xyzi16")
+        sensors.append(SensorCloud(data=data, n=n_per_sensor, q_xyzw=qj / np.linalg.norm(qj), t_xyz=tj, **lay))
+    return sensors, MergeParams(leaf=(0.05,) * 3, min_points_per_voxel=min_pts)
+
+
+def config3_dense(n_per_sensor=2_000_000, n_sensors=8, min_pts=0, leaf=0.02):
+    """cfg3's sensors, box and leaf with the points drawn INSIDE the reference ROI (about 85 % survive the crop instead of
+    4 %): 13-14 M records of 29-bit indices enter the sort — the LDS/sort stress BASELINE.json's configs[2] names.
+    Vehicle-mounted sensors (yaw-only poses); every sensor sees the whole corridor."""
+    sensors = []
+    lo, hi = np.asarray(REF_ROI_MIN, np.float64), np.asarray(REF_ROI_MAX, np.float64)
+    for s in range(n_sensors):
+        rng = _rng(3501 + s)
+        yaw = rng.uniform(-np.pi, np.pi)
+        q = yaw_quaternion(yaw)
+        t = rng.uniform(-2, 2, 3)
+        ng = int(round(0.7 * n_per_sensor))
+        w = np.empty((n_per_sensor, 3))
+        ext = hi - lo
+        w[:, 0] = rng.uniform(lo[0] - 0.04 * ext[0], hi[0] + 0.04 * ext[0], n_per_sensor)      # ~8 % fall outside in x,
+        w[:, 1] = rng.uniform(lo[1] - 0.04 * ext[1], hi[1] + 0.04 * ext[1], n_per_sensor)      # ~8 % in y
+        w[:ng, 2] = rng.normal(0.0, 0.03, ng)                                                  # a road surface at z = 0
+        w[ng:, 2] = rng.uniform(lo[2], hi[2], n_per_sensor - ng)
+        # into the sensor frame: p_sensor = R^T (p_world - t)
+        c, sn = np.cos(yaw), np.sin(yaw)
+        d = w - t
+        xyz = np.stack([c * d[:, 0] + sn * d[:, 1], -sn * d[:, 0] + c * d[:, 1], d[:, 2]], axis=1).astype(np.float32)
+        inten = rng.uniform(0.0, 255.0, n_per_sensor).astype(np.float32)
+        perm = rng.permutation(n_per_sensor)
+        data, lay = pack(xyz[perm], inten[perm], "xyzi16")
+        sensors.append(SensorCloud(data=data, n=n_per_sensor, q_xyzw=q, t_xyz=t, **lay))
+    return sensors, MergeParams(leaf=(leaf,) * 3, min_points_per_voxel=min_pts,
+                                crop_min=REF_ROI_MIN, crop_max=REF_ROI_MAX)
+
+
 def config3(n_per_sensor=2_000_000, n_sensors=8, min_pts=0, leaf=0.02):
     """8 x 2 M, yaw-only rotations, reference ROI crop, 2 cm voxel."""
     sensors = []

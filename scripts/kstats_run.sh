@@ -4,7 +4,7 @@ TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 rm -rf gpurun_out/${TAG}_prof
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_prof -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --inflight 1 "$@" > gpurun_out/${TAG}_prof_bench.json 2> gpurun_out/${TAG}_prof.err || { tail -5 gpurun_out/${TAG}_prof.err; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_prof -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-e2e --inflight 1 "$@" > gpurun_out/${TAG}_prof_bench.json 2> gpurun_out/${TAG}_prof.err || { tail -5 gpurun_out/${TAG}_prof.err; exit 1; }
 f=$(find gpurun_out/${TAG}_prof -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/${TAG}_inflight1_kernel_stats.csv
 python3 - <<PY
 import json,csv,re

@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from cloud_merger_amd import capi, synth
-for leaf in (0.02, 0.05, 0.2, 0.5, 2.0):
+for leaf in (0.02, 0.05, 0.1, 0.2, 0.5, 1.0, 2.0, 5.0):
     sensors, params = synth.config2(min_pts=0)
     params.leaf = (leaf,) * 3
     with capi.CloudMerger(max_points_total=4_000_000, max_sensors=4, flags=capi.FLAG_PROFILE) as cm:
@@ -14,3 +14,4 @@ for leaf in (0.02, 0.05, 0.2, 0.5, 2.0):
             r = cm.merge_voxelize(params)
             rows.append((r.path_flags, r.sort_passes, round(r.device_ms * 1e3)))
         print(f"leaf {leaf}: status {r.status} n_out {r.n_out} key_bits {r.key_bits} (flags, passes, us) per frame: {rows}")
+        print("      last frame:", {n_: round(ms * 1e3, 1) for n_, ms in cm.stage_times()})

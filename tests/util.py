@@ -95,3 +95,23 @@ def assert_centroids_close_or_exact(got, want, counts, cells, merged, leaf, sequ
     d_want = float(np.abs(want[is_big][:, :3].astype(np.float64) - exact).max())
     assert d_got <= 1e-4, f"centroid of a voxel of more than {big} points is {d_got} m off the exact mean (oracle: {d_want})"
     return d_got, d_want
+
+
+# k3_local (the bucket path's finish) adds a voxel's points one after the other — pcl's own order, bit for bit — as long as
+# the voxel's run of sorted positions ends within 16 positions of its owner thread's block: always for voxels of up to
+# 17 points. Longer runs may be finished by a wave that adds 64 points per step in a fixed tree order (deterministic,
+# within the north-star tolerance, not bit-identical to the sequential sum).
+SEQ_EXACT_MAX = 17
+
+
+def assert_bucket_centroids(got, want, counts, cells=None, merged=None, leaf=None):
+    """Bucket path with the k3_local finish: bit-exact for voxels of up to SEQ_EXACT_MAX points, assert_centroids_close
+    (or, with the merged cloud at hand, the exact-mean rule for voxels of more than 1000 points) for the rest."""
+    got, want, counts = np.asarray(got), np.asarray(want), np.asarray(counts)
+    small = counts <= SEQ_EXACT_MAX
+    assert same_bits(got[small], want[small]), "voxels of up to 17 points: one summation order, bit for bit"
+    if (~small).any():
+        if merged is not None:
+            assert_centroids_close_or_exact(got, want, counts, cells, merged, leaf, sequential=False)
+        else:
+            assert_centroids_close(got[~small], want[~small])
