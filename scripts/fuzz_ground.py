@@ -93,7 +93,7 @@ with capi.CloudMerger(max_points_total=CAP, max_sensors=6, flags=capi.FLAG_OCCUP
         if st == oracle.OK:
             assert np.array_equal(g["cells"], rep.cells) and np.array_equal(g["counts"], rep.counts), ctx
             assert_centroids_close_or_exact(a4(g["out"]), xyzi_of(vox), rep.counts, rep.cells, want_ng, params.leaf,
-                                            sequential=bool(g["res"].path_flags & 2))
+                                            sequential=bool(g["res"].path_flags & 2) and not (g["res"].path_flags & 32))
         n_packed += int(bool(g["res"].path_flags & 16))
         frame += 1
         if frame % 10 == 0:
