@@ -554,11 +554,11 @@ void cmk3_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t*
                 uint32_t n_padded) {
     const dim3 grid(n_padded / 2048);
     if (partial)
-        hipLaunchKernelGGL((k3_local<2048, 3968, 512, 8, true>), grid, dim3(512), 0, s, fd, st, host_state,
+        hipLaunchKernelGGL((k3_local<2048, 4096, 512, 6, true>), grid, dim3(512), 0, s, fd, st, host_state,
                            reinterpret_cast<const float4*>(rec), reinterpret_cast<uint2*>(tile_info), grp_cnt,
                            reinterpret_cast<float4*>(stage), nullptr, nullptr, low_bits);
     else
-        hipLaunchKernelGGL((k3_local<2048, 3968, 512, 8, false>), grid, dim3(512), 0, s, fd, st, host_state,
+        hipLaunchKernelGGL((k3_local<2048, 4096, 512, 6, false>), grid, dim3(512), 0, s, fd, st, host_state,
                            reinterpret_cast<const float4*>(rec), reinterpret_cast<uint2*>(tile_info), grp_cnt,
                            reinterpret_cast<float4*>(stage), stage_key, stage_cnt, low_bits);
 }

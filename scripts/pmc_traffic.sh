@@ -1,4 +1,5 @@
 #!/bin/bash
+# usage: [MP=0] [BENCH_ARGS="--config 3 --dense"] pmc_traffic.sh TAG
 # HBM traffic of one frame from the PMC counters (separate rocprofv3 --pmc passes, as
 # MI355X_MICROARCH.md §HBM prescribes). Writes gpurun_out/${TAG}_traffic.json.
 TAG=${1:-pmc}
@@ -7,7 +8,7 @@ mkdir -p gpurun_out
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/${TAG}_$C
   timeout -k 10 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/${TAG}_$C -- \
-      python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --profile-frames 2 --min-pts ${MP:-2} > gpurun_out/${TAG}_$C.json 2> gpurun_out/${TAG}_$C.err || { tail -5 gpurun_out/${TAG}_$C.err; exit 1; }
+      python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-e2e --profile-frames 2 --min-pts ${MP:-2} ${BENCH_ARGS:-} > gpurun_out/${TAG}_$C.json 2> gpurun_out/${TAG}_$C.err || { tail -5 gpurun_out/${TAG}_$C.err; exit 1; }
 done
 python3 - "$TAG" <<'PY'
 import csv, glob, json, re, sys, collections
@@ -18,12 +19,12 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     per = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
         if r.get("Counter_Name") != c: continue
-        m = re.search(r"(k2?_\w+)", r["Kernel_Name"])
+        m = re.search(r"(k[23]?_\w+)", r["Kernel_Name"])
         if not m: continue
         per[m.group(1)][0] += float(r["Counter_Value"]); per[m.group(1)][1] += 1
     res[c] = {k: {"sum_kb": v[0], "dispatches": v[1]} for k, v in per.items()}
 bench = json.load(open(f"gpurun_out/{tag}_FETCH_SIZE.json"))
-frames = max(res["FETCH_SIZE"].get("k_keys", {"dispatches": 0})["dispatches"], res["FETCH_SIZE"].get("k2_local", {"dispatches": 0})["dispatches"])
+frames = max(res["FETCH_SIZE"].get(k, {"dispatches": 0})["dispatches"] for k in ("k_keys", "k2_local", "k3_local"))
 out = {"frames": frames, "unit": "bytes per frame", "kernels": {},
        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KB -> bytes). gfx950 FETCH_SIZE "
                "counts wide coalesced reads at half their bytes (MI355X_MICROARCH.md): 'fetch_x2' doubles it; narrower "
