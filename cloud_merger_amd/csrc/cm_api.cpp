@@ -412,15 +412,24 @@ int build_frame(cm_ctx* c, const cm_params* p, bool consume, std::vector<std::un
 
 int launch_classic(cm_ctx* c, const cm_params* p, int mode, int grid_mode, uint32_t key_bits, bool outl, int gm_o,
                    uint32_t kb_o);
+uint32_t bucket_passes(uint32_t kb, uint64_t est, uint32_t extra);
 
 // Bounds of the merged cloud by one k_minmax pass and a host round trip: only when the bucket path
 // has no box yet (first frame of a context without a crop box, or after a point left the predicted box).
 void set_predicted_box(cm_ctx* c, const float mn[3], const float mx[3], const float leaf[3]) {
-    for (int a = 0; a < 3; ++a) {
-        const float ext = mx[a] - mn[a];
-        const float margin = std::max(ext / 8.0f, 8.0f * leaf[a]);
-        c->pred_min[a] = mn[a] - margin;
-        c->pred_max[a] = mx[a] + margin;
+    // A cloud near the limit of PCL's 32-bit index leaves no room for an eighth of its extent on every side: take what
+    // fits (a frame right behind one that reached far out would otherwise lose its box, and with it the bucket path).
+    float inv[3];
+    for (int a = 0; a < 3; ++a) inv[a] = 1.0f / leaf[a];
+    for (float part = 8.0f; part <= 1024.0f; part *= 2.0f) {
+        for (int a = 0; a < 3; ++a) {
+            const float ext = mx[a] - mn[a];
+            const float margin = std::max(ext / part, (part <= 8.0f ? 8.0f : 2.0f) * leaf[a]);
+            c->pred_min[a] = mn[a] - margin;
+            c->pred_max[a] = mx[a] + margin;
+        }
+        uint32_t kb = 0;
+        if (box_grid(c->pred_min, c->pred_max, inv, &kb)) break;
     }
     c->pred_ok = true;
 }
@@ -433,6 +442,19 @@ void update_predicted_box(cm_ctx* c, const float mn[3], const float mx[3], const
         const float margin = std::max((mx[a] - mn[a]) / 8.0f, 8.0f * leaf[a]);
         const float lo = mn[a] - c->pred_min[a], hi = c->pred_max[a] - mx[a];
         redo = !(lo >= margin / 4.0f && lo <= 3.0f * margin && hi >= margin / 4.0f && hi <= 3.0f * margin);
+    }
+    if (!redo) {
+        // ... and not a box so much larger than the cloud needs that it costs a global pass: after a frame that reached
+        // far out the box would otherwise stay wide — and the index one digit longer — for as long as the cloud fits it
+        float inv[3], tmin[3], tmax[3];
+        for (int a = 0; a < 3; ++a) {
+            inv[a] = 1.0f / leaf[a];
+            const float margin = std::max((mx[a] - mn[a]) / 8.0f, 8.0f * leaf[a]);
+            tmin[a] = mn[a] - margin; tmax[a] = mx[a] + margin;
+        }
+        uint32_t kb_now = 0, kb_tight = 0;
+        if (box_grid(c->pred_min, c->pred_max, inv, &kb_now) && box_grid(tmin, tmax, inv, &kb_tight))
+            redo = bucket_passes(kb_tight, 0, 0) < bucket_passes(kb_now, 0, 0);
     }
     if (redo) set_predicted_box(c, mn, mx, leaf);
 }
