@@ -294,3 +294,48 @@ def test_cfg5_runner_two_processes_gloo_on_one_gpu():
     assert out["n_gpus"] == 2 and out["config"]["points_per_frame"] == 16 * 150000
     assert out["parity"]["occupancy_bit_exact"] and out["parity"]["max_abs_dxyz_m"] <= 1e-4
     assert out["config"]["gathered_entries"] >= out["config"]["voxels_out"] > 0
+
+
+def _splitmix_clouds(n_sensors, n_points, seed=5001):
+    """The generator of cloud_merger_amd/host/fused_main.cpp, vectorised: sensor s draws 4 values per point from
+    splitmix64(seed + s) — x, y, z uniform in the cfg5 crop box widened by 10 %, intensity in [0, 255)."""
+    from cloud_merger_amd.types import xyzi_cloud
+    cmin, cmax = np.array([-15.0, -5.0, -0.5], np.float32), np.array([45.0, 5.0, 3.0], np.float32)
+    clouds = []
+    for s in range(n_sensors):
+        st = np.uint64(seed + s) + np.uint64(0x9E3779B97F4A7C15) * np.arange(1, 4 * n_points + 1, dtype=np.uint64)
+        z = st
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+        u = ((z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)).reshape(n_points, 4)
+        ext = cmax - cmin
+        xyz = (cmin - np.float32(0.05) * ext) + (np.float32(1.1) * ext) * u[:, :3]          # fp32 arithmetic, as in the tool
+        clouds.append(xyzi_cloud(xyz.astype(np.float32), (np.float32(255.0) * u[:, 3]).astype(np.float32)))
+    return clouds
+
+
+@pytest.mark.gpu
+def test_cpp_fused_tool_world1_matches_the_oracle(tmp_path):
+    """cloudmerge_fused (C++: C-ABI + RCCL called directly, one process per GPU) with one rank: ncclCommInitRank through the
+    file rendezvous, both all-gathers, cm_merge_partial -> cm_merge_tables; its fused cloud against the oracle on the same
+    sensors (regenerated here with the tool's splitmix64 stream). More ranks need more GPUs: the driver's node."""
+    import json
+    import subprocess
+    from cloud_merger_amd import build as cm_build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cm_build.build()
+    subprocess.run(["make", "-C", os.path.join(root, "cloud_merger_amd", "host"), "-s"], check=True)
+    n_sensors, n_points, leaf, min_pts = 16, 40_000, 0.05, 2
+    r = subprocess.run([os.path.join(root, "cloud_merger_amd", "host", "bin", "cloudmerge_fused"), "--rank", "0", "--world", "1",
+                        "--rendezvous", str(tmp_path / "id"), "--sensors", str(n_sensors), "--points", str(n_points),
+                        "--leaf", str(leaf), "--min-pts", str(min_pts), "--steps", "3"],
+                       capture_output=True, text=True, timeout=300, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    sensors = _splitmix_clouds(n_sensors, n_points)
+    params = MergeParams(leaf=(leaf,) * 3, min_points_per_voxel=min_pts, crop_min=(-15.0, -5.0, -0.5), crop_max=(45.0, 5.0, 3.0))
+    st, _, ref, rep = oracle.merge_voxelize(sensors, params, threads=4, stable=True)
+    assert st == oracle.OK and got["status"] == 0 and got["voxels_out"] == rep.n_out > 0
+    want = float((ref["x"].astype(np.float64) + 2.0 * ref["y"] + 3.0 * ref["z"] + 5.0 * ref["intensity"]).sum())
+    assert abs(got["checksum"] - want) <= 1e-4 * rep.n_out * 10, (got["checksum"], want)
