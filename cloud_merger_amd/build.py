@@ -19,7 +19,7 @@ HEADERS = ["cm_device.h", "cm_kernels.h", "cm_common.hpp", os.path.join("..", ".
 # -ffp-contract=off / -fno-fast-math: occupancy must match the reference bit for bit, so no FMA
 # contraction on the device or in the host-side quaternion/grid arithmetic (SURVEY.md §7 hard part 1).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-fvisibility=hidden",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical", "-fvisibility=hidden",
          "-Wl,-rpath,/opt/rocm/lib"]
 
 

@@ -534,9 +534,9 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
     CmFrameDev& f = c->frame;
     hipStream_t st = c->stream;
     { const int e = bucket_buffers(c); if (e != CM_OK) return e; }
-    if (!c->frame_uploaded_valid || std::memcmp(&f, &c->frame_uploaded, sizeof f) != 0) {
-        prof_mark(c, "k_setup");
-        cmk_setup(st, f, c->d_frame, c->d_tiles);
+    // (a descriptor that changed since the last frame — new clouds, new poses — goes to HBM with k2_hist0 itself)
+    const bool do_setup = !c->frame_uploaded_valid || std::memcmp(&f, &c->frame_uploaded, sizeof f) != 0;
+    if (do_setup) {
         c->frame_uploaded = f;
         c->frame_uploaded_valid = true;
     }
@@ -559,7 +559,7 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
     const bool pack = !predicted && pack_survivors(c);
     c->last_packed = pack;
     prof_mark(c, "k2_hist0");
-    cmk2_hist0(st, c->d_frame, c->d_tiles, state, c->hist, grp0, grp0_next, c->grp + 2 * gstride, gw, static_cast<uint32_t>(gstride),
+    cmk2_hist0(st, f, c->d_frame, c->d_tiles, do_setup, state, c->hist, grp0, grp0_next, c->grp + 2 * gstride, gw, static_cast<uint32_t>(gstride),
                c->tile_state, f.n_padded / 1024 + 2, c->records, grid_mode, predicted ? 1 : 0, low_bits, n_global, nt, mask,
                st_outlier, 0, pack ? c->rec_b : nullptr, c->wave_cnt);
     for (uint32_t pass = 0; pass < n_global; ++pass) {
@@ -715,6 +715,9 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
         }
         if (gm == 1 && !box_grid(p->crop_min, p->crop_max, inv_leaf, &kb, f.box_min_b, f.box_div_b)) gm = 0;
         if (gm == 2 && mode == 1 && !box_grid(bounds, bounds + 3, inv_leaf, &kb, f.box_min_b, f.box_div_b)) gm = 0;
+        // (the bucket kernels form the linear index on the 24-bit multiplier: fewer than 2^24 cells per axis)
+        for (int a = 0; a < 3 && gm != 0; ++a)
+            if (f.box_div_b[a] >= (1 << 24)) gm = 0;
         if (gm != 0) {
             f.box_key_bits = kb;
             f.box_predicted = (gm == 2 && mode == 0) ? 1u : 0u;
@@ -728,7 +731,8 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
                 c->post_bucket = true; c->post_g = g; c->post_low = low;
                 // the outlier stage's own sort can use the bucket kernels as well: the crop box fixes its grid too
                 c->pre_bucket = gm_o == 1 && box_grid(p->crop_min, p->crop_max, inv_cell, &kb_o, f.cell_min_b, f.cell_div_b) &&
-                                static_cast<uint64_t>(f.cell_div_b[1]) * static_cast<uint64_t>(f.cell_div_b[2]) <= CM_ROW_TABLE_CAP;
+                                static_cast<uint64_t>(f.cell_div_b[1]) * static_cast<uint64_t>(f.cell_div_b[2]) <= CM_ROW_TABLE_CAP &&
+                                f.cell_div_b[0] < (1 << 24) && f.cell_div_b[1] < (1 << 24) && f.cell_div_b[2] < (1 << 24);
                 f.cell_key_bits = kb_o; f._pad_cell = 0;
                 if (c->pre_bucket && c->pre_bucket_off) { --c->pre_bucket_off; c->pre_bucket = false; }
             }
@@ -811,7 +815,7 @@ int launch_classic(cm_ctx* c, const cm_params* p, int mode, int grid_mode, uint3
             ++c->frame_seq;
             const bool pack = pack_survivors(c);
             prof_mark(c, "k2_hist0(outlier)");
-            cmk2_hist0(st, c->d_frame, c->d_tiles, c->d_state_o, c->hist, grp0, grp0_next, c->grp + 2 * gstride, gw, static_cast<uint32_t>(gstride),
+            cmk2_hist0(st, f, c->d_frame, c->d_tiles, false, c->d_state_o, c->hist, grp0, grp0_next, c->grp + 2 * gstride, gw, static_cast<uint32_t>(gstride),
                        c->tile_state, f.n_padded / 1024 + 2, c->records, 1, 0, low, g, nt, in, nullptr, 1,
                        pack ? c->rec_b : nullptr, c->wave_cnt);
             for (uint32_t pass = 0; pass < g; ++pass) {

@@ -173,6 +173,21 @@ __device__ __forceinline__ void load_tile_points(const CmSensorDev& sd, uint32_t
     }
 }
 
+// A point of the two aligned layouts at a 32-bit byte offset from a wave-uniform base (the tile's first point: the
+// offset stays below CM_TILE * 32 bytes), so that the address is scalar base + one VGPR, not a 64-bit multiply-add per load.
+template <int LAYOUT>
+__device__ __forceinline__ Pt load_point_near(const unsigned char* __restrict__ data_generic, uint32_t idx) {
+    cm_gptr data = (cm_gptr)data_generic;
+    typedef const CM_GLOBAL_AS cm_v4f* f4ptr;
+    typedef const CM_GLOBAL_AS float* f1ptr;
+    Pt p;
+    const uint32_t off = idx * (LAYOUT == CM_LAYOUT_XYZI16 ? 16u : 32u);
+    const cm_v4f v = *(f4ptr)(data + off);
+    p.x = v.x; p.y = v.y; p.z = v.z; p.i = v.w;
+    if (LAYOUT == CM_LAYOUT_PCL32) p.i = *(f1ptr)(data + off + 16u);
+    return p;
+}
+
 // The same from a tile entry (k_setup): `first` counts from the tile's first point.
 template <int LAYOUT, int N>
 __device__ __forceinline__ void load_tile_raw(const unsigned char* __restrict__ data, uint32_t n, uint32_t step, uint32_t ox,
@@ -181,7 +196,8 @@ __device__ __forceinline__ void load_tile_raw(const unsigned char* __restrict__ 
 #pragma unroll
     for (int r = 0; r < N; ++r) {
         const uint32_t i = first + r * 64;
-        p[r] = load_point(data, LAYOUT, step, ox, oy, oz, oi, i < n ? i : n - 1);
+        if (LAYOUT == CM_LAYOUT_GENERIC) p[r] = load_point(data, LAYOUT, step, ox, oy, oz, oi, i < n ? i : n - 1);
+        else p[r] = load_point_near<LAYOUT>(data, i < n ? i : n - 1);
     }
 #pragma unroll
     for (int r = 0; r < N; ++r) {
@@ -293,6 +309,56 @@ __device__ __forceinline__ void compute_grid(const CmFrameDev* __restrict__ fd,
     while (bits < 32 && (cells - 1) >> bits) ++bits;
     g.key_bits = bits;
     g.n_passes = (bits + CM_RADIX_BITS - 1) / CM_RADIX_BITS;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The box grid of the bucket path (crop box / predicted box; cm_api.cpp box_grid) and the cell of a point in it.
+// ------------------------------------------------------------------------------------------------
+struct BoxGrid {
+    float inv0, inv1, inv2, fb0, fb1, fb2;
+    uint32_t d0, d1, d2;
+    uint32_t mul1, mul2l, mul2h;      // cells per x row; cells per z level = mul2h << 12 | mul2l
+};
+
+// use_cell: the radius grid of the outlier stage instead of the voxel grid
+__device__ __forceinline__ BoxGrid box_grid_of(const CmFrameDev* __restrict__ fd, int use_cell = 0) {
+    BoxGrid b;
+    const int32_t* min_b = use_cell ? fd->cell_min_b : fd->box_min_b;
+    const int32_t* div_b = use_cell ? fd->cell_div_b : fd->box_div_b;
+    const float* inv = use_cell ? fd->inv_cell : fd->inv_leaf;
+    b.inv0 = inv[0]; b.inv1 = inv[1]; b.inv2 = inv[2];
+    b.fb0 = static_cast<float>(min_b[0]); b.fb1 = static_cast<float>(min_b[1]); b.fb2 = static_cast<float>(min_b[2]);
+    b.d0 = static_cast<uint32_t>(div_b[0]); b.d1 = static_cast<uint32_t>(div_b[1]); b.d2 = static_cast<uint32_t>(div_b[2]);
+    b.mul1 = b.d0;
+    const uint32_t mul2 = b.d0 * b.d1;
+    b.mul2l = mul2 & 0xFFFu; b.mul2h = mul2 >> 12;
+    return b;
+}
+
+// Linear index c0 + c1 * d0 + c2 * d0 * d1 (mod 2^32; exact for a cell of the box: the host only takes the bucket
+// path when the box has fewer than 2^32 cells and fewer than 2^24 per axis — cm_api.cpp) on the full-rate 24-bit
+// multiplier: v_mul_lo_u32 / v_mad_u64_u32 run at a quarter of the rate, and the index is formed several times per point.
+__device__ __forceinline__ uint32_t box_index(const BoxGrid& b, uint32_t c0, uint32_t c1, uint32_t c2) {
+    uint32_t hi = __umul24(c2, b.mul2h);
+    asm("" : "+v"(hi));               // (keeps the shift behind the product: folded into the factor it would need the 32-bit multiplier again)
+    return c0 + __umul24(c1, b.mul1) + __umul24(c2, b.mul2l) + (hi << 12);
+}
+
+// Cell of a transformed point, PCL's arithmetic (A.4 step 5). `inside`: the cell lies in the box (false for a
+// non-finite coordinate as well: NaN converts to 0, so finiteness is asked separately by the callers that need it).
+__device__ __forceinline__ uint32_t key_of(const BoxGrid& b, float x, float y, float z, bool* inside) {
+    const uint32_t c0 = static_cast<uint32_t>(static_cast<int>(__fsub_rn(floorf(__fmul_rn(x, b.inv0)), b.fb0)));
+    const uint32_t c1 = static_cast<uint32_t>(static_cast<int>(__fsub_rn(floorf(__fmul_rn(y, b.inv1)), b.fb1)));
+    const uint32_t c2 = static_cast<uint32_t>(static_cast<int>(__fsub_rn(floorf(__fmul_rn(z, b.inv2)), b.fb2)));
+    *inside = (c0 < b.d0) & (c1 < b.d1) & (c2 < b.d2);          // (unsigned: a negative cell is a huge one)
+    return box_index(b, c0, c1, c2);
+}
+// ... of a record known to lie in the box
+__device__ __forceinline__ uint32_t key_of(const BoxGrid& b, const float4& r) {
+    const uint32_t c0 = static_cast<uint32_t>(static_cast<int>(__fsub_rn(floorf(__fmul_rn(r.x, b.inv0)), b.fb0)));
+    const uint32_t c1 = static_cast<uint32_t>(static_cast<int>(__fsub_rn(floorf(__fmul_rn(r.y, b.inv1)), b.fb1)));
+    const uint32_t c2 = static_cast<uint32_t>(static_cast<int>(__fsub_rn(floorf(__fmul_rn(r.z, b.inv2)), b.fb2)));
+    return box_index(b, c0, c1, c2);
 }
 
 struct Acc { float x, y, z, i; uint32_t c; };

@@ -45,7 +45,8 @@ void cmk_merged(hipStream_t s, const CmFrameDev* fd, uint32_t* tile_counts, uint
                 uint32_t n_tiles, const unsigned char* mask);
 
 // ---- bucket path (cm_kernels_v2.hip) --------------------------------------------------------
-void cmk2_hist0(hipStream_t s, const CmFrameDev* fd, const CmTileDev* tiles, CmFrameState* st, uint32_t* hist, uint32_t* grp_acc,
+// (f by value: the kernel reads the descriptor from its arguments; do_setup: it also leaves f in *fd and the tile table in tiles)
+void cmk2_hist0(hipStream_t s, const CmFrameDev& f, CmFrameDev* fd, CmTileDev* tiles, bool do_setup, CmFrameState* st, uint32_t* hist, uint32_t* grp_acc,
                 uint32_t* grp_clear_a, uint32_t* grp_clear_b, uint32_t n_group_words, uint32_t n_clear_a_words,
                 unsigned long long* tile_state, uint32_t n_tile_state, float* records, int grid_mode, int check_box,
                 uint32_t shift0, uint32_t n_global_passes, uint32_t n_tiles, const unsigned char* mask,

@@ -63,40 +63,6 @@ __device__ __forceinline__ uint32_t block_sum_w(uint32_t v, uint32_t* lds) {
     return tot;
 }
 
-// The box grid k2_hist0 recorded in the frame state (compute_grid on the crop box / predicted box).
-struct BoxGrid {
-    float inv0, inv1, inv2, fb0, fb1, fb2;
-    int d0, d1, d2;
-    uint32_t mul1, mul2;
-};
-
-// use_cell: the radius grid of the outlier stage instead of the voxel grid
-__device__ __forceinline__ BoxGrid box_grid_of(const CmFrameDev* __restrict__ fd, int use_cell = 0) {
-    BoxGrid b;
-    const int32_t* min_b = use_cell ? fd->cell_min_b : fd->box_min_b;
-    const int32_t* div_b = use_cell ? fd->cell_div_b : fd->box_div_b;
-    const float* inv = use_cell ? fd->inv_cell : fd->inv_leaf;
-    b.inv0 = inv[0]; b.inv1 = inv[1]; b.inv2 = inv[2];
-    b.fb0 = static_cast<float>(min_b[0]); b.fb1 = static_cast<float>(min_b[1]); b.fb2 = static_cast<float>(min_b[2]);
-    b.d0 = div_b[0]; b.d1 = div_b[1]; b.d2 = div_b[2];
-    b.mul1 = static_cast<uint32_t>(div_b[0]);
-    b.mul2 = b.mul1 * static_cast<uint32_t>(div_b[1]);
-    return b;
-}
-
-// Cell of a transformed point, PCL's arithmetic (A.4 step 5). `inside`: the cell lies in the box.
-__device__ __forceinline__ uint32_t key_of(const BoxGrid& b, float x, float y, float z, bool* inside) {
-    const int c0 = static_cast<int>(__fsub_rn(floorf(__fmul_rn(x, b.inv0)), b.fb0));
-    const int c1 = static_cast<int>(__fsub_rn(floorf(__fmul_rn(y, b.inv1)), b.fb1));
-    const int c2 = static_cast<int>(__fsub_rn(floorf(__fmul_rn(z, b.inv2)), b.fb2));
-    *inside = c0 >= 0 && c0 < b.d0 && c1 >= 0 && c1 < b.d1 && c2 >= 0 && c2 < b.d2;
-    return static_cast<uint32_t>(c0) + static_cast<uint32_t>(c1) * b.mul1 + static_cast<uint32_t>(c2) * b.mul2;
-}
-__device__ __forceinline__ uint32_t key_of(const BoxGrid& b, const float4& r) {
-    bool in;
-    return key_of(b, r.x, r.y, r.z, &in);
-}
-
 // x / c for a point count c (an integer below 2^16) given rc = RN(1/c): quotient estimate, exact
 // residual by FMA, one correction — the correctly rounded x / c that pcl::VoxelGrid's float division
 // gives (A.4 step 6) whenever x / c is a normal number; inf / NaN sums pass through unchanged.
@@ -119,8 +85,9 @@ __device__ __forceinline__ uint32_t sensor_of_slot(const CmFrameDev* __restrict_
 // Also clears what the later kernels of this frame (and the first kernel of the next) accumulate into.
 // ------------------------------------------------------------------------------------------------
 template <bool PACK>
-__global__ __launch_bounds__(CM2_BLOCK, PACK ? 8 : 1) void k2_hist0(const CmFrameDev* __restrict__ fd,
-                                                      const CmTileDev* __restrict__ tiles,
+__global__ __launch_bounds__(CM2_BLOCK, PACK ? 8 : 1) void k2_hist0(const CmFrameDev fv,
+                                                      CmFrameDev* __restrict__ fd_dst,
+                                                      CmTileDev* __restrict__ tiles_dst, int do_setup,
                                                       CmFrameState* __restrict__ st,
                                                       uint32_t* __restrict__ hist,
                                                       uint32_t* __restrict__ grp_acc,
@@ -134,6 +101,9 @@ __global__ __launch_bounds__(CM2_BLOCK, PACK ? 8 : 1) void k2_hist0(const CmFram
                                                       const unsigned char* __restrict__ mask,
                                                       const CmFrameState* __restrict__ st_outlier, int use_cell,
                                                       float4* __restrict__ compact_out, uint32_t* __restrict__ wave_cnt) {
+    // The frame descriptor arrives by value (kernel arguments). do_setup (it changed since the context's last frame:
+    // new clouds, new poses): this kernel also leaves it in HBM for the kernels behind it, with the tile table — what
+    // a launch of k_setup in front of every frame of a moving stream used to do (6 us on a frame's critical path).
     // compact_out (frames whose crop box drops most points): the surviving records are written here as well, wave w of
     // tile t packing its own in slot order at [t * 4096 + w * 512, ...) and leaving their number in wave_cnt[t * 8 + w];
     // the first scatter then reads these few records instead of every raw point a second time.
@@ -142,6 +112,24 @@ __global__ __launch_bounds__(CM2_BLOCK, PACK ? 8 : 1) void k2_hist0(const CmFram
     __shared__ uint32_t s_cnt[CM2_WAVES];
     __shared__ uint32_t s_out;
     const uint32_t tile = blockIdx.x;
+    const CmFrameDev* __restrict__ fd = &fv;
+    CmTileDev te;                                         // where this tile's points lie (k_setup's arithmetic)
+    {
+        const uint32_t first = tile * CM_TILE;
+        uint32_t k = 0;
+        for (uint32_t q = 1; q < fv.n_sensors; ++q) k += (first >= fv.s[q].base) ? 1u : 0u;
+        const CmSensorDev& sd0 = fv.s[k];
+        const uint32_t off = first - sd0.base;
+        te.data = sd0.data + static_cast<size_t>(off) * sd0.point_step;
+        te.n_left = sd0.n > off ? sd0.n - off : 0u;
+        te.info = k | (sd0.layout << 8);
+    }
+    if (do_setup) {
+        static_assert(sizeof(CmFrameDev) % 4 == 0 && sizeof(CmFrameDev) / 4 <= CM2_BLOCK, "one word of the descriptor per thread");
+        if (threadIdx.x == 0) tiles_dst[tile] = te;
+        if (tile == 0 && threadIdx.x < sizeof(CmFrameDev) / 4)
+            reinterpret_cast<uint32_t*>(fd_dst)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&fv)[threadIdx.x];
+    }
     for (uint32_t k = tile * CM2_BLOCK + threadIdx.x; k < 3 * n_group_words; k += gridDim.x * CM2_BLOCK) grp_clear_b[k] = 0;
     for (uint32_t k = tile * CM2_BLOCK + threadIdx.x; k < n_clear_a_words; k += gridDim.x * CM2_BLOCK) grp_clear_a[k] = 0;
     for (uint32_t k = tile * CM2_BLOCK + threadIdx.x; k < n_tile_state; k += gridDim.x * CM2_BLOCK) tile_state[k] = 0ull;
@@ -164,7 +152,6 @@ __global__ __launch_bounds__(CM2_BLOCK, PACK ? 8 : 1) void k2_hist0(const CmFram
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t slot0 = tile * CM_TILE + w * (64 * CM2_ITEMS) + lane;
-    const CmTileDev te = tiles[tile];                     // (one dependent load to the tile's points; the matrix comes meanwhile)
     const CmSensorDev& sd = fd->s[te.info & 0xFFu];
     Pt p[CM2_ITEMS];
     load_tile_te<CM2_ITEMS>(te, sd, w * (64 * CM2_ITEMS) + lane, p);
@@ -172,8 +159,18 @@ __global__ __launch_bounds__(CM2_BLOCK, PACK ? 8 : 1) void k2_hist0(const CmFram
 #pragma unroll
     for (int k = 0; k < 12; ++k) m[k] = sd.m[k];
     const uint32_t crop = fd->crop_enable;
+    float cmn0 = 0.f, cmn1 = 0.f, cmn2 = 0.f, cmx0 = 0.f, cmx1 = 0.f, cmx2 = 0.f;
+    if (crop) {
+        cmn0 = fd->crop_min[0]; cmn1 = fd->crop_min[1]; cmn2 = fd->crop_min[2];
+        cmx0 = fd->crop_max[0]; cmx1 = fd->crop_max[1]; cmx2 = fd->crop_max[2];
+    }
     if (threadIdx.x < CM_RADIX) lh[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_out = 0;
+    uint32_t mk[CM2_ITEMS];                               // keep-mask bytes of the pre-stages (outlier / ground removal)
+    if (mask) {
+#pragma unroll
+        for (int r = 0; r < CM2_ITEMS; ++r) mk[r] = mask[slot0 + r * 64];
+    }
     __syncthreads();
     const float inf = __uint_as_float(0x7F800000u);
     float mn0 = inf, mn1 = inf, mn2 = inf, mx0 = -inf, mx1 = -inf, mx2 = -inf;
@@ -181,27 +178,27 @@ __global__ __launch_bounds__(CM2_BLOCK, PACK ? 8 : 1) void k2_hist0(const CmFram
     bool any_out = false;
     const bool all_fields = fd->downsample_all != 0;
     uint32_t wrun = 0;                                    // records this wave has packed so far (wave-uniform)
+    // Straight-line code per point: every test is formed as a flag (no short-circuit evaluation — the compiler turns
+    // that into a chain of exec-mask branches with the running min/max re-materialised at every join), and only the
+    // LDS add sits under a mask.
+    float tx[CM2_ITEMS], ty[CM2_ITEMS], tz[CM2_ITEMS];
+    uint32_t okm = 0;
 #pragma unroll
     for (int r = 0; r < CM2_ITEMS; ++r) {
         const float x = xf_row(m[0], m[1], m[2], m[3], p[r].x, p[r].y, p[r].z);
         const float y = xf_row(m[4], m[5], m[6], m[7], p[r].x, p[r].y, p[r].z);
         const float z = xf_row(m[8], m[9], m[10], m[11], p[r].x, p[r].y, p[r].z);
-        bool keep = false;
-        if (point_valid(x, y, z, crop, fd->crop_min, fd->crop_max) && (!mask || mask[slot0 + r * 64])) {
-            bool in;
-            const uint32_t key = key_of(b, x, y, z, &in);
-            if (predicted) {                              // a crop box holds every valid point by construction
-                any_out = any_out || !in;
-                mn0 = fminf(mn0, x); mx0 = fmaxf(mx0, x);
-                mn1 = fminf(mn1, y); mx1 = fmaxf(mx1, y);
-                mn2 = fminf(mn2, z); mx2 = fmaxf(mx2, z);
-                ++cnt;
-            } else {
-                in = true;
-            }
-            if (in) atomicAdd(&lh[(key >> shift0) & (CM_RADIX - 1)], 1u);
-            keep = in;
-        }
+        tx[r] = x; ty[r] = y; tz[r] = z;
+        bool ok = finite_f32(x) & finite_f32(y) & finite_f32(z);
+        if (crop) ok = ok & !((x < cmn0) | (x > cmx0) | (y < cmn1) | (y > cmx1) | (z < cmn2) | (z > cmx2));
+        if (mask) ok = ok & (mk[r] != 0u);
+        bool in;
+        const uint32_t key = key_of(b, x, y, z, &in);
+        if (predicted) any_out = any_out | (ok & !in);     // a crop box holds every valid point by construction
+        else in = true;
+        const bool keep = ok & in;
+        okm |= ok ? (1u << r) : 0u;
+        if (keep) atomicAdd(&lh[(key >> shift0) & (CM_RADIX - 1)], 1u);
         if (PACK) {
             const unsigned long long bal = __ballot(keep);
             if (keep) {
@@ -210,6 +207,27 @@ __global__ __launch_bounds__(CM2_BLOCK, PACK ? 8 : 1) void k2_hist0(const CmFram
                     make_float4(x, y, z, use_cell ? __uint_as_float(slot0 + r * 64) : (all_fields ? p[r].i : 0.f));
             }
             wrun += static_cast<uint32_t>(__popcll(bal));
+        }
+    }
+    if (predicted) {
+        // The exact bounds of the valid points (pcl::getMinMax3D). Nearly every wave holds valid points only: then the
+        // eight values of a lane fold with three-operand min / max, no masking.
+        cnt = static_cast<uint32_t>(__builtin_popcount(okm));
+        if (__ballot(okm != (1u << CM2_ITEMS) - 1u) == 0ull) {
+#pragma unroll
+            for (int r = 0; r < CM2_ITEMS; r += 2) {
+                mn0 = fminf(fminf(mn0, tx[r]), tx[r + 1]); mx0 = fmaxf(fmaxf(mx0, tx[r]), tx[r + 1]);
+                mn1 = fminf(fminf(mn1, ty[r]), ty[r + 1]); mx1 = fmaxf(fmaxf(mx1, ty[r]), ty[r + 1]);
+                mn2 = fminf(fminf(mn2, tz[r]), tz[r + 1]); mx2 = fmaxf(fmaxf(mx2, tz[r]), tz[r + 1]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < CM2_ITEMS; ++r) {
+                const bool ok = (okm >> r) & 1u;
+                mn0 = fminf(mn0, ok ? tx[r] : inf); mx0 = fmaxf(mx0, ok ? tx[r] : -inf);
+                mn1 = fminf(mn1, ok ? ty[r] : inf); mx1 = fmaxf(mx1, ok ? ty[r] : -inf);
+                mn2 = fminf(mn2, ok ? tz[r] : inf); mx2 = fmaxf(mx2, ok ? tz[r] : -inf);
+            }
         }
     }
     if (PACK && lane == 0) wave_cnt[tile * CM2_WAVES + w] = wrun;
@@ -314,6 +332,8 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __r
     // resident at once (with three per CU the last 209 tiles ran as a second, nearly empty generation)
     __shared__ float4 srec[CM_TILE / 2];                // staging in two halves
     __shared__ uint32_t whist[CM2_WAVES][CM_RADIX / 2]; // digit counts per wave, two 16-bit counters per word (a wave ranks 512 records)
+    uint16_t* sdig = reinterpret_cast<uint16_t*>(&whist[0][0]);   // once the ranks are known: this pass's digit | the next one's << 8 of every staged record
+    static_assert(sizeof(uint32_t) * CM2_WAVES * (CM_RADIX / 2) >= sizeof(uint16_t) * (CM_TILE / 2), "digit pairs fit the counters");
     __shared__ uint32_t gofs[CM_RADIX];
     __shared__ uint16_t s_dbase[CM_RADIX];
     __shared__ uint32_t lds[CM2_WAVES];
@@ -365,7 +385,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __r
     }
 
     float4 rec[CM2_ITEMS];
-    uint32_t lp[CM2_ITEMS];                               // digit, then digit | rank << 16, then the position in the sorted tile
+    uint32_t lp[CM2_ITEMS];                               // digit | next pass's digit << 8, then | rank << 16, then position in the sorted tile | digits << 16
     uint32_t vmask = 0;
     Pt p[CM2_ITEMS];                                      // (first pass: the raw points)
     uint32_t sidx = 0;
@@ -385,7 +405,8 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __r
         for (int r = 0; r < CM2_ITEMS; ++r) {
             const uint32_t i = r * 64 + lane;
             rec[r] = src[i < cw ? i : 0u];                 // (unconditional load; slot 0 of the wave's range is always mapped)
-            lp[r] = (key_of(b, rec[r]) >> shift) & (CM_RADIX - 1);
+            const uint32_t k = key_of(b, rec[r]);
+            lp[r] = ((k >> shift) & (CM_RADIX - 1)) | (next_shift < 32u ? ((k >> next_shift) & 0xFFu) << 8 : 0u);
             if (i < cw) vmask |= 1u << r;
         }
     } else if (FIRST) {
@@ -398,6 +419,15 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __r
             const uint32_t i = first + r * 64;
             rec[r] = (i < n_padded) ? rec_in[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        // The last pass needs no index at all: its digit is the byte the pass before left beside every record (dig_out is
+        // only written by passes that have a successor, so nobody writes the array while this pass reads it).
+        if (next_shift >= 32u) {
+#pragma unroll
+            for (int r = 0; r < CM2_ITEMS; ++r) {
+                const uint32_t i = first + r * 64;
+                lp[r] = (i < n_padded) ? dig_out[i] : 0u;
+            }
+        }
     }
 
     if (FIRST && !compact_in) {
@@ -406,6 +436,11 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __r
 #pragma unroll
         for (int k = 0; k < 12; ++k) m[k] = sd.m[k];
         const uint32_t crop = fd->crop_enable;
+        float cmn0 = 0.f, cmn1 = 0.f, cmn2 = 0.f, cmx0 = 0.f, cmx1 = 0.f, cmx2 = 0.f;
+        if (crop) {
+            cmn0 = fd->crop_min[0]; cmn1 = fd->crop_min[1]; cmn2 = fd->crop_min[2];
+            cmx0 = fd->crop_max[0]; cmx1 = fd->crop_max[1]; cmx2 = fd->crop_max[2];
+        }
         const bool all_fields = fd->downsample_all != 0;
 #pragma unroll
         for (int r = 0; r < CM2_ITEMS; ++r) {
@@ -413,12 +448,15 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __r
             rec[r].y = xf_row(m[4], m[5], m[6], m[7], p[r].x, p[r].y, p[r].z);
             rec[r].z = xf_row(m[8], m[9], m[10], m[11], p[r].x, p[r].y, p[r].z);
             rec[r].w = use_cell ? __uint_as_float(first + r * 64) : (all_fields ? p[r].i : 0.f);   // outlier stage: the point's padded index rides along
-            bool in = false;
-            lp[r] = 0;
-            if (point_valid(rec[r].x, rec[r].y, rec[r].z, crop, fd->crop_min, fd->crop_max) &&
-                (!mask || mask[first + r * 64]))
-                lp[r] = (key_of(b, rec[r].x, rec[r].y, rec[r].z, &in) >> shift) & (CM_RADIX - 1);
-            if (in) vmask |= 1u << r;
+            bool ok = finite_f32(rec[r].x) & finite_f32(rec[r].y) & finite_f32(rec[r].z);
+            if (crop) ok = ok & !((rec[r].x < cmn0) | (rec[r].x > cmx0) | (rec[r].y < cmn1) | (rec[r].y > cmx1) |
+                                  (rec[r].z < cmn2) | (rec[r].z > cmx2));
+            if (mask) ok = ok & (mask[first + r * 64] != 0);        // (frames behind a pre-stage only)
+            bool in;
+            const uint32_t k = key_of(b, rec[r].x, rec[r].y, rec[r].z, &in);
+            ok = ok & in;
+            lp[r] = ok ? ((k >> shift) & (CM_RADIX - 1)) | (next_shift < 32u ? ((k >> next_shift) & 0xFFu) << 8 : 0u) : 0u;
+            vmask |= ok ? (1u << r) : 0u;
         }
     }
 
@@ -433,16 +471,30 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __r
     if (!FIRST) {
 #pragma unroll
         for (int r = 0; r < CM2_ITEMS; ++r) {
-            lp[r] = (key_of(b, rec[r]) >> shift) & (CM_RADIX - 1);
+            if (next_shift < 32u) {                              // (uniform; the last pass has its digits already)
+                const uint32_t k = key_of(b, rec[r]);
+                lp[r] = ((k >> shift) & (CM_RADIX - 1)) | (((k >> next_shift) & 0xFFu) << 8);
+            }
             if (first + r * 64 < n) vmask |= 1u << r;
         }
     }
     for (uint32_t q = threadIdx.x; q < CM2_WAVES * CM_RADIX / 2; q += CM2_BLOCK) (&whist[0][0])[q] = 0;
     __syncthreads();
+    // The returning adds go out one behind the other (a slot without a record adds nothing), the ranks are taken once all
+    // are back: under a branch each the wave waited for every single one.
 #pragma unroll
-    for (int r = 0; r < CM2_ITEMS; ++r) {
-        const uint32_t sh = (lp[r] & 1u) * 16u;
-        if (vmask >> r & 1u) lp[r] |= ((atomicAdd(&whist[w][lp[r] >> 1], 1u << sh) >> sh) & 0xFFFFu) << 16;
+    for (int r0 = 0; r0 < CM2_ITEMS; r0 += 4) {               // (four at a time: eight returns in flight cost registers the records need)
+        uint32_t got[4];
+#pragma unroll
+        for (int r = r0; r < r0 + 4; ++r) {
+            const uint32_t sh = (lp[r] & 1u) * 16u;
+            got[r - r0] = atomicAdd(&whist[w][(lp[r] & 0xFFu) >> 1], (vmask >> r & 1u) << sh);
+        }
+#pragma unroll
+        for (int r = r0; r < r0 + 4; ++r) {
+            lp[r] |= ((got[r - r0] >> ((lp[r] & 1u) * 16u)) & 0xFFFFu) << 16;
+            asm volatile("" : "+v"(lp[r]));                 // (formed here, not where it is next used: the raw returns would have to stay alive)
+        }
     }
     __syncthreads();
     PH((FIRST ? 0 : 8) + 2);
@@ -477,37 +529,45 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __r
 #pragma unroll
     for (int r = 0; r < CM2_ITEMS; ++r) {
         const uint32_t digit = lp[r] & 0xFFu;
-        lp[r] = (vmask >> r & 1u) ? ((whist[w][digit >> 1] >> ((digit & 1u) * 16u)) & 0xFFFFu) + (lp[r] >> 16) : 0xFFFFFFFFu;
+        const uint32_t wv = whist[w][digit >> 1];               // (read whether the slot holds a record or not: no branch)
+        const uint32_t at = ((wv >> ((digit & 1u) * 16u)) & 0xFFFFu) + (lp[r] >> 16);
+        lp[r] = ((vmask >> r & 1u) ? at : 0xFFFFu) | (lp[r] << 16);
+        asm volatile("" : "+v"(lp[r]));
     }
-    // Two rounds through the staging buffer: sorted positions [0, 2048), then [2048, 4096).
+    // Two rounds through the staging buffer: sorted positions [0, 2048), then [2048, 4096). Beside every record goes its
+    // pair of digits (where the counters were: they are read out by now), so that whoever carries the record to HBM
+    // neither forms its index a second time nor needs the grid.
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const uint32_t lo = h * (CM_TILE / 2);
         if (h == 1) {
             PH((FIRST ? 0 : 8) + 4);
             if (tile_valid <= lo) break;                   // uniform
-            __syncthreads();
         }
+        __syncthreads();                                   // (round 0: the last reads of the counters; round 1: of the staged records)
 #pragma unroll
         for (int r = 0; r < CM2_ITEMS; ++r)
-            if (lp[r] - lo < CM_TILE / 2) srec[lp[r] - lo] = rec[r];
+            if ((lp[r] & 0xFFFFu) - lo < CM_TILE / 2) {
+                srec[(lp[r] & 0xFFFFu) - lo] = rec[r];
+                sdig[(lp[r] & 0xFFFFu) - lo] = static_cast<uint16_t>(lp[r] >> 16);
+            }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < CM2_ITEMS / 2; ++j) {
             const uint32_t t = lo + j * CM2_BLOCK + threadIdx.x;
             if (t < tile_valid) {
                 const float4 r4 = srec[t - lo];
-                const uint32_t k = key_of(b, r4);
-                uint32_t pos = gofs[(k >> shift) & (CM_RADIX - 1)] + t;
+                const uint32_t dd = sdig[t - lo];
+                uint32_t pos = gofs[dd & 0xFFu] + t;
                 if (debug_swap && tile == 0 && h == 0 && tile_valid > 1) {
                     const uint32_t last = min(tile_valid, static_cast<uint32_t>(CM_TILE / 2)) - 1u;   // (both in the first staging round)
                     if (t == 0 || t == last) {
                         const uint32_t to = t == 0 ? last : 0u;
-                        pos = gofs[(key_of(b, srec[to]) >> shift) & (CM_RADIX - 1)] + to;
+                        pos = gofs[sdig[to] & 0xFFu] + to;
                     }
                 }
                 rec_out[pos] = r4;
-                if (next_shift < 32u) dig_out[pos] = static_cast<unsigned char>((k >> next_shift) & 0xFFu);
+                if (next_shift < 32u) dig_out[pos] = static_cast<unsigned char>(dd >> 8);
             }
         }
     }
@@ -948,17 +1008,17 @@ extern "C" __attribute__((visibility("default"))) void cm_debug_phases(unsigned 
 }
 #endif
 
-void cmk2_hist0(hipStream_t s, const CmFrameDev* fd, const CmTileDev* tiles, CmFrameState* st, uint32_t* hist, uint32_t* grp_acc,
+void cmk2_hist0(hipStream_t s, const CmFrameDev& f, CmFrameDev* fd, CmTileDev* tiles, bool do_setup, CmFrameState* st, uint32_t* hist, uint32_t* grp_acc,
                 uint32_t* grp_clear_a, uint32_t* grp_clear_b, uint32_t n_group_words, uint32_t n_clear_a_words,
                 unsigned long long* tile_state, uint32_t n_tile_state, float* records, int grid_mode, int check_box,
                 uint32_t shift0, uint32_t n_global_passes, uint32_t n_tiles, const unsigned char* mask,
                 const CmFrameState* st_outlier, int use_cell, void* compact_out, uint32_t* wave_cnt) {
     if (compact_out)
-        hipLaunchKernelGGL(k2_hist0<true>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, hist, grp_acc, grp_clear_a, grp_clear_b,
+        hipLaunchKernelGGL(k2_hist0<true>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, f, fd, tiles, do_setup ? 1 : 0, st, hist, grp_acc, grp_clear_a, grp_clear_b,
                            n_group_words, n_clear_a_words, tile_state, n_tile_state, records, grid_mode, check_box, shift0,
                            n_global_passes, mask, st_outlier, use_cell, reinterpret_cast<float4*>(compact_out), wave_cnt);
     else
-        hipLaunchKernelGGL(k2_hist0<false>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, hist, grp_acc, grp_clear_a, grp_clear_b,
+        hipLaunchKernelGGL(k2_hist0<false>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, f, fd, tiles, do_setup ? 1 : 0, st, hist, grp_acc, grp_clear_a, grp_clear_b,
                            n_group_words, n_clear_a_words, tile_state, n_tile_state, records, grid_mode, check_box, shift0,
                            n_global_passes, mask, st_outlier, use_cell, nullptr, nullptr);
 }

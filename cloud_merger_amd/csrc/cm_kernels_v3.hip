@@ -31,26 +31,6 @@
 
 namespace {
 
-struct BoxGrid3 {
-    float inv0, inv1, inv2, fb0, fb1, fb2;
-    uint32_t mul1, mul2;
-};
-__device__ __forceinline__ BoxGrid3 box_grid3(const CmFrameDev* __restrict__ fd) {
-    BoxGrid3 b;
-    b.inv0 = fd->inv_leaf[0]; b.inv1 = fd->inv_leaf[1]; b.inv2 = fd->inv_leaf[2];
-    b.fb0 = static_cast<float>(fd->box_min_b[0]); b.fb1 = static_cast<float>(fd->box_min_b[1]);
-    b.fb2 = static_cast<float>(fd->box_min_b[2]);
-    b.mul1 = static_cast<uint32_t>(fd->box_div_b[0]);
-    b.mul2 = b.mul1 * static_cast<uint32_t>(fd->box_div_b[1]);
-    return b;
-}
-// Cell of a record, PCL's arithmetic (A.4 step 5); the record is known to lie in the box.
-__device__ __forceinline__ uint32_t key3(const BoxGrid3& b, const float4& r) {
-    const int c0 = static_cast<int>(__fsub_rn(floorf(__fmul_rn(r.x, b.inv0)), b.fb0));
-    const int c1 = static_cast<int>(__fsub_rn(floorf(__fmul_rn(r.y, b.inv1)), b.fb1));
-    const int c2 = static_cast<int>(__fsub_rn(floorf(__fmul_rn(r.z, b.inv2)), b.fb2));
-    return static_cast<uint32_t>(c0) + static_cast<uint32_t>(c1) * b.mul1 + static_cast<uint32_t>(c2) * b.mul2;
-}
 __device__ __forceinline__ float div_by_count3(float x, float c, float rc) {   // see div_by_count (cm_kernels_v2.hip)
     const float q = __fmul_rn(x, rc);
     const float r = __fmaf_rn(-q, c, x);
@@ -67,6 +47,8 @@ __device__ __forceinline__ float wave_sum_f32_fixed(float v) {
 #undef CM3_FADD
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+
+#define SCAL(x) static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(x)))
 
 struct Job3 {                      // a voxel that runs far past its owner's block: finished by a whole wave
     uint32_t p, key, kid, cnt;     // next sorted position, the voxel's key, its number among the tile's kept voxels, points so far
@@ -132,7 +114,6 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
     PH3_START();
     // (values that are the same in every lane are put into scalar registers by hand — the compiler cannot tell for what
     // comes out of LDS or global memory — so that the loops below branch and count on the scalar unit)
-#define SCAL(x) static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(x)))
     const int lane = threadIdx.x & 63;
     const uint32_t w = SCAL(threadIdx.x >> 6);
     if (st->status != CM_DEV_OK || st->outside) return;          // (k3_compact reports)
@@ -140,7 +121,7 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
     const uint32_t n_lt = (n + LT - 1) / LT;
     const uint32_t tile = blockIdx.x;
     if (tile >= n_lt) return;
-    const BoxGrid3 b = box_grid3(fd);
+    const BoxGrid b = box_grid_of(fd);
     const uint32_t L = low_bits;
     const uint32_t min_pts = SCAL((!PARTIAL && fd->min_pts > 1) ? fd->min_pts : 1u);
 
@@ -162,10 +143,10 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const uint32_t q = r * LBLOCK + threadIdx.x;
-            if (q < nom) sk[q] = key3(b, r4[r]);
+            if (q < nom) sk[q] = key_of(b, r4[r]);
         }
-        if (has_e) sk[LT + threadIdx.x] = key3(b, e4);
-        if (threadIdx.x == 0) { s_keyprev = base > 0 ? key3(b, pv) : 0u; s_a = 0xFFFFFFFFu; s_bad = 0u; s_njobs = 0u; }
+        if (has_e) sk[LT + threadIdx.x] = key_of(b, e4);
+        if (threadIdx.x == 0) { s_keyprev = base > 0 ? key_of(b, pv) : 0u; s_a = 0xFFFFFFFFu; s_bad = 0u; s_njobs = 0u; }
     }
     __syncthreads();
     PH3(0);
@@ -204,7 +185,7 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
             bool mm = false;
             if (j < n) {
                 const float4 r4 = rec[j];
-                const uint32_t k = key3(b, r4);
+                const uint32_t k = key_of(b, r4);
                 mm = (k >> L) == h_last;
                 bad_order = bad_order || (k >> L) < h_last;
                 if (mm && pos < LCAP) sk[pos] = k;
@@ -466,7 +447,7 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
 #pragma unroll
                 for (int u = 0; u < JU; ++u) {
                     if (ended) break;                          // (uniform)
-                    if (L == 0) in[u] = in[u] && key3(b, r4[u]) == jkey;
+                    if (L == 0) in[u] = in[u] && key_of(b, r4[u]) == jkey;
                     const unsigned long long bal = __ballot(in[u]);
                     if (!in[u]) r4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                     ax = __fadd_rn(ax, wave_sum_f32_fixed(r4[u].x)); ay = __fadd_rn(ay, wave_sum_f32_fixed(r4[u].y));

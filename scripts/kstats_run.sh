@@ -12,6 +12,6 @@ d=json.load(open("gpurun_out/${TAG}_prof_bench.json"))
 print("ms/step %.4f alone t_dev_ms %.4f M=%d"%(d["ms_per_step"], d["roofline"]["one_frame_alone"]["t_device_ms"], d["config"]["voxels_out"]))
 rows=list(csv.DictReader(open("gpurun_out/${TAG}_inflight1_kernel_stats.csv")))
 for r in rows[:12]:
-    m=re.search(r"(k[23g]?_\w+(<[\w, ]+>)?|__amd\w+)", r["Name"]); nm=m.group(1) if m else r["Name"][:30]
+    m=re.search(r"(k[234g]?_\w+(<[\w, ]+>)?|__amd\w+)", r["Name"]); nm=m.group(1) if m else r["Name"][:30]
     print("%-40s calls %5s avg_us %8.2f"%(nm, r["Calls"], float(r["AverageNs"])/1e3))
 PY

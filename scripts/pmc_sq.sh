@@ -18,7 +18,7 @@ for i in (1,2):
     f=glob.glob(f"gpurun_out/{tag}_p{i}/**/*counter_collection.csv", recursive=True)[0]
     seen=set()
     for r in csv.DictReader(open(f)):
-        m=re.search(r"(k[23]?_\w+)", r["Kernel_Name"])
+        m=re.search(r"(k[234]?_\w+)", r["Kernel_Name"])
         if not m: continue
         k=m.group(1)
         acc[k][r["Counter_Name"]]+=float(r["Counter_Value"])
