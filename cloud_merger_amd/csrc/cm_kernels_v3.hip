@@ -414,20 +414,25 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
             }
         }
 
-        // ---- long voxels: wave w takes jobs w, w + LWAVES, ... 64 positions per step, every record of a step fetched at
-        // once, the step's sum formed in a fixed tree order and added to the running sum step after step: deterministic,
-        // within 1e-4 m of pcl's one-after-the-other sum (closer to the exact mean, in fact), not bit-identical to it.
+        // ---- long voxels. A wave sums 64 positions per chunk, eight chunks (512 positions) per step: every record of a step
+        // asked for at once, a chunk's sum formed in a fixed tree order and added to the running sum chunk after chunk:
+        // deterministic, within 1e-4 m of pcl's one-after-the-other sum (closer to the exact mean, in fact), not
+        // bit-identical to it. Normally wave w takes jobs w, w + LWAVES, ... whole; with fewer jobs than waves in a tile
+        // whose voxels average 512 points or more (coarse grids: a tile's records are a voxel or two of thousands of
+        // points, and the tiles behind it have nothing of their own to do) all waves share every job — wave w takes the
+        // steps w, w + LWAVES, ... of it — and their partial sums are added in wave order.
         __syncthreads();
         const uint32_t njobs = SCAL(s_njobs);
-        for (uint32_t jn = w; jn < njobs; jn += LWAVES) {
+        const bool coop = !(njobs >= static_cast<uint32_t>(LWAVES) || m < 512u * max(c_t, 1u));   // (uniform)
+        Job3* part = jobs + 64;                                // (coop: fewer than LWAVES jobs — room for the waves' partial sums)
+        for (uint32_t jn = coop ? 0u : w; jn < njobs; jn += coop ? 1u : static_cast<uint32_t>(LWAVES)) {
             const Job3 jb = jobs[jn];
-            uint32_t p = SCAL(jb.p), cnj = SCAL(jb.cnt);
             const uint32_t jkey = SCAL(jb.key);
-            float ax = jb.sx, ay = jb.sy, az = jb.sz, aw = jb.sw;
+            uint32_t p = SCAL(jb.p) + (coop ? w * (64u * 8u) : 0u), cnj = coop ? 0u : SCAL(jb.cnt);
+            const uint32_t stride = coop ? LWAVES * 64u * 8u : 64u * 8u;
+            float ax = coop ? 0.f : jb.sx, ay = coop ? 0.f : jb.sy, az = coop ? 0.f : jb.sz, aw = coop ? 0.f : jb.sw;
             bool ended = false;
-            while (!ended) {
-                // eight chunks of 64 positions per step: all their records asked for at once, then chunk after chunk
-                // reduced in a fixed tree order and added to the running sum
+            while (!ended) {                                   // the steps p, p + stride, ... of the run until it ends
                 constexpr int JU = 8;
                 float4 r4[JU];
                 bool in[JU];
@@ -453,12 +458,30 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
                     ax = __fadd_rn(ax, wave_sum_f32_fixed(r4[u].x)); ay = __fadd_rn(ay, wave_sum_f32_fixed(r4[u].y));
                     az = __fadd_rn(az, wave_sum_f32_fixed(r4[u].z)); aw = __fadd_rn(aw, wave_sum_f32_fixed(r4[u].w));
                     cnj += static_cast<uint32_t>(__popcll(bal));
-                    ended = bal != ~0ull;                      // the run ended inside this chunk
+                    ended = bal != ~0ull;                      // the run ended inside this chunk (or before this step)
                 }
-                p += 64 * JU;
-                if (cnj > CM3_RUN_MAX) { if (lane == 0) host_state[offsetof(CmFrameState, err) / 4] = CM_DEV_ERR_BUCKET; break; }
+                p += stride;
+                if (cnj > CM3_RUN_MAX) break;
             }
-            if (lane == 0) emit(SCAL(jb.kid), jkey, ax, ay, az, aw, cnj);
+            if (!coop) {
+                if (cnj > CM3_RUN_MAX && lane == 0) host_state[offsetof(CmFrameState, err) / 4] = CM_DEV_ERR_BUCKET;
+                if (lane == 0) emit(SCAL(jb.kid), jkey, ax, ay, az, aw, cnj);
+            } else {                                           // (every wave is here: jn and njobs are the same for all)
+                if (lane == 0) { Job3 pr; pr.p = 0; pr.key = 0; pr.kid = 0; pr.cnt = cnj; pr.sx = ax; pr.sy = ay; pr.sz = az; pr.sw = aw; part[w] = pr; }
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    float tx = jb.sx, ty = jb.sy, tz = jb.sz, tw = jb.sw;
+                    uint32_t tc = jb.cnt;
+#pragma unroll
+                    for (int q = 0; q < LWAVES; ++q) {
+                        tx = __fadd_rn(tx, part[q].sx); ty = __fadd_rn(ty, part[q].sy); tz = __fadd_rn(tz, part[q].sz); tw = __fadd_rn(tw, part[q].sw);
+                        tc += part[q].cnt;
+                    }
+                    if (tc > CM3_RUN_MAX) host_state[offsetof(CmFrameState, err) / 4] = CM_DEV_ERR_BUCKET;
+                    emit(jb.kid, jkey, tx, ty, tz, tw, tc);
+                }
+                __syncthreads();
+            }
         }
     }
     PH3(3);

@@ -14,4 +14,7 @@ for leaf in (0.02, 0.05, 0.1, 0.2, 0.5, 1.0, 2.0, 5.0):
             r = cm.merge_voxelize(params)
             rows.append((r.path_flags, r.sort_passes, round(r.device_ms * 1e3)))
         print(f"leaf {leaf}: status {r.status} n_out {r.n_out} key_bits {r.key_bits} (flags, passes, us) per frame: {rows}")
-        print("      last frame:", {n_: round(ms * 1e3, 1) for n_, ms in cm.stage_times()})
+        acc = {}
+        for n_, ms in cm.stage_times():                       # (a stage launched several times: launches x mean)
+            acc.setdefault(n_, []).append(ms * 1e3)
+        print("      last frame:", {n_: (f"{len(v)} x {sum(v) / len(v):.1f}" if len(v) > 1 else round(v[0], 1)) for n_, v in acc.items()})
