@@ -30,7 +30,7 @@
 #define CM2_BLOCK 512         // threads per workgroup in the record passes (8 wave64, 8 points each)
 #define CM2_WAVES 8
 #define CM2_ITEMS 8
-// (the local finish's geometry — 2048-record tiles, room for 4096, 512 threads — is fixed where it is launched: cmk2_local)
+// (the local finish's geometry — 2048-record tiles, room for 4032 (k3_local) / 4096 (k2_local), 512 threads — is fixed where it is launched)
 #define CM2_MAX_LOW_BITS 14   // key bits left to the local finish when the global passes allow it
 
 // Point layouts the loaders special-case.

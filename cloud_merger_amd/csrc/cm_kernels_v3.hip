@@ -556,13 +556,16 @@ extern "C" __attribute__((visibility("default"))) void cm_debug_phases3(unsigned
 void cmk3_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* host_state, const void* rec, void* tile_info,
                 uint32_t* grp_cnt, void* stage, uint32_t* stage_key, uint32_t* stage_cnt, bool partial, uint32_t low_bits,
                 uint32_t n_padded) {
+    // 2048-record tiles, room for 4032 (bucket tails of up to 1984 records), 512 threads at no more than 64 registers:
+    // 40 912 bytes of LDS — four workgroups per CU, all eight wave slots of every SIMD (44 us at cfg2; with room for 4096 the
+    // fourth workgroup does not fit the CU's 160 KiB: 47 us)
     const dim3 grid(n_padded / 2048);
     if (partial)
-        hipLaunchKernelGGL((k3_local<2048, 4096, 512, 6, true>), grid, dim3(512), 0, s, fd, st, host_state,
+        hipLaunchKernelGGL((k3_local<2048, 4032, 512, 8, true>), grid, dim3(512), 0, s, fd, st, host_state,
                            reinterpret_cast<const float4*>(rec), reinterpret_cast<uint2*>(tile_info), grp_cnt,
                            reinterpret_cast<float4*>(stage), nullptr, nullptr, low_bits);
     else
-        hipLaunchKernelGGL((k3_local<2048, 4096, 512, 6, false>), grid, dim3(512), 0, s, fd, st, host_state,
+        hipLaunchKernelGGL((k3_local<2048, 4032, 512, 8, false>), grid, dim3(512), 0, s, fd, st, host_state,
                            reinterpret_cast<const float4*>(rec), reinterpret_cast<uint2*>(tile_info), grp_cnt,
                            reinterpret_cast<float4*>(stage), stage_key, stage_cnt, low_bits);
 }
