@@ -487,8 +487,11 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __r
         uint32_t got[4];
 #pragma unroll
         for (int r = r0; r < r0 + 4; ++r) {
+            // (a slot without a record adds nothing — to a word of its own: the LDS serialises same-address adds of a
+            // wave, and in a frame that a crop box empties nearly every lane would meet on one counter)
             const uint32_t sh = (lp[r] & 1u) * 16u;
-            got[r - r0] = atomicAdd(&whist[w][(lp[r] & 0xFFu) >> 1], (vmask >> r & 1u) << sh);
+            const bool has = vmask >> r & 1u;
+            got[r - r0] = atomicAdd(&whist[w][has ? (lp[r] & 0xFFu) >> 1 : static_cast<uint32_t>(lane)], (has ? 1u : 0u) << sh);
         }
 #pragma unroll
         for (int r = r0; r < r0 + 4; ++r) {

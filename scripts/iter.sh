@@ -12,9 +12,10 @@ fi
 bash scripts/kstats_run.sh ${TAG} || exit 1
 timeout -k 10 200 python bench.py --no-cpu-baseline --no-e2e --static > gpurun_out/${TAG}_bench_static.json 2> gpurun_out/${TAG}_bench.err || { tail -20 gpurun_out/${TAG}_bench.err; exit 1; }
 timeout -k 10 200 python bench.py --no-cpu-baseline --no-e2e > gpurun_out/${TAG}_bench_moving.json 2>> gpurun_out/${TAG}_bench.err || { tail -20 gpurun_out/${TAG}_bench.err; exit 1; }
+timeout -k 10 200 python bench.py --no-cpu-baseline --no-e2e --config 3 > gpurun_out/${TAG}_bench_cfg3.json 2>> gpurun_out/${TAG}_bench.err || { tail -20 gpurun_out/${TAG}_bench.err; exit 1; }
 python3 - <<PY
 import json
-for n in ("static","moving"):
+for n in ("static","moving","cfg3"):
     d=json.load(open("gpurun_out/${TAG}_bench_%s.json"%n))
     print("%-7s ms/step %.4f frac %.4f alone %.4f ms redone %s parity %s"%(n,d["ms_per_step"],d["roofline"]["frac"],d["roofline"]["one_frame_alone"]["t_device_ms"],d["config"].get("redone_frames"),d.get("parity")))
 PY
