@@ -735,6 +735,43 @@ def test_bucket_path_one_to_three_global_passes(leaf, half, n_pass, sort_path):
         assert g["res"].path_flags & BUCKET and g["res"].sort_passes == n_pass
 
 
+def test_axis_of_more_than_2_24_cells_takes_the_general_path(sort_path):
+    """The bucket kernels form the linear voxel index on the 24-bit multiplier (cm_common.hpp box_index): a box with
+    2^24 cells or more along one axis is refused by the host and the frame takes the general path — same result."""
+    rng = np.random.default_rng(24)
+    n = 20_000
+    xyz = np.stack([rng.uniform(0.0, 20.0, n), rng.uniform(0.0, 0.9, n), rng.uniform(0.0, 0.9, n)], axis=1).astype(np.float32)
+    xyz[: n // 2, 0] = np.round(xyz[: n // 2, 0], 3)          # (some voxels with more than one point)
+    sensors = [xyzi_cloud(xyz, rng.uniform(0, 255, n))]
+    params = MergeParams(leaf=(1e-6, 1.0, 1.0), min_points_per_voxel=0, crop_min=(0.0, 0.0, 0.0), crop_max=(20.0, 1.0, 1.0))
+    g, rep = check_against_oracle(sensors, params)
+    assert g["res"].status == capi.OK and int(rep.div_b[0]) >= (1 << 24)
+    assert not (g["res"].path_flags & BUCKET)
+
+
+def test_cloud_in_scan_order(sort_path):
+    """A spinning lidar delivers its points ring by ring, azimuth by azimuth: neighbours in memory are neighbours in space
+    (the synthetic scenes are randomly permuted). Lanes of a wave then meet on the same LDS counters and voxels arrive as
+    runs; two frames, the second one in the box predicted from the first."""
+    sensors, params = synth.config2(n_per_sensor=60_000, min_pts=2)
+    ordered = []
+    for s in sensors:
+        a = s.data
+        ring = np.floor(np.degrees(np.arctan2(a["z"], np.hypot(a["x"], a["y"]))) / 0.4).astype(np.int64)
+        order = np.lexsort((np.arctan2(a["y"], a["x"]), ring))
+        ordered.append(SensorCloud(data=np.ascontiguousarray(a[order]), n=s.n, q_xyzw=s.q_xyzw, t_xyz=s.t_xyz))
+    st, merged, out, rep = oracle.merge_voxelize(ordered, params, threads=4, stable=True)
+    n_total = sum(s.n for s in ordered)
+    with capi.CloudMerger(max_points_total=n_total, max_sensors=4, flags=capi.FLAG_OCCUPANCY) as cm:
+        for frame in range(2):
+            g = run_gpu(ordered, params, cm=cm)
+            assert g["res"].status == st == capi.OK and g["res"].n_out == rep.n_out
+            assert np.array_equal(g["cells"], rep.cells) and np.array_equal(g["counts"], rep.counts)
+            assert_centroids_close(g["out"], xyzi_of(out))
+        if sort_path == "auto":
+            assert g["res"].path_flags & BUCKET
+
+
 def test_mis_ranked_global_pass_is_noticed_and_redone(sort_path, monkeypatch):
     """the bucket path relies on lane-ordered returning LDS adds for its stable ranking (probed once
     at cm_create). The finish checks what the global passes hand it — the bucket number must not decrease from one
