@@ -924,6 +924,37 @@ int launch_classic(cm_ctx* c, const cm_params* p, int mode, int grid_mode, uint3
     return CM_OK;
 }
 
+// A frame of the bucket path whose predicted box a point left: k2_hist0 measured the cloud's exact bounds all the same
+// (its per-tile records, folded by the first scatter's workgroup 0 before it left), so the frame is redone at once in a box
+// around those — on the bucket path again, without the general path's min/max pass. false: not applicable (the caller
+// redoes the frame on the general path).
+bool redo_in_measured_box(cm_ctx* c, const CmFrameState& h0) {
+    if (!h0.outside || h0.err || !c->last_predicted || c->last_mode != 0 || c->frame_mask || c->last_outl || c->ground_on ||
+        c->path_mode == 1 || !c->lds_rank || h0.n_valid_k0 == 0 || c->frame.n_padded == 0)
+        return false;
+    CmFrameDev& f = c->frame;
+    float leaf[3], inv_leaf[3];
+    for (int a = 0; a < 3; ++a) {
+        if (!std::isfinite(h0.min_p[a]) || !std::isfinite(h0.max_p[a]) || h0.min_p[a] > h0.max_p[a]) return false;
+        leaf[a] = c->last_params.leaf[a];
+        inv_leaf[a] = f.inv_leaf[a];
+    }
+    set_predicted_box(c, h0.min_p, h0.max_p, leaf);
+    uint32_t kb = 0;
+    if (!box_grid(c->pred_min, c->pred_max, inv_leaf, &kb, f.box_min_b, f.box_div_b)) { c->pred_ok = false; return false; }
+    for (int a = 0; a < 3; ++a) {
+        if (f.box_div_b[a] >= (1 << 24)) return false;
+        f.ext_min[a] = c->pred_min[a]; f.ext_max[a] = c->pred_max[a];
+    }
+    f.box_key_bits = kb;
+    f.box_predicted = 1u;
+    const uint32_t g = bucket_passes(kb, h0.n_valid_k0, c->v2_extra_passes);
+    if (!g) return false;
+    c->h_state->err = 0;
+    c->prof_used = 0;
+    return launch_bucket(c, 2, g, kb > 8 * g ? kb - 8 * g : 0, nullptr, nullptr, 0) == CM_OK;
+}
+
 int wait_frame(cm_ctx* c, cm_result* res) {
     if (!c) return CM_BAD_ARG;
     if (!c->pending) return fail(c, CM_BAD_ARG, "no frame enqueued");
@@ -968,6 +999,15 @@ int wait_frame(cm_ctx* c, cm_result* res) {
                 if (h0.err == CM_DEV_ERR_LOOKBACK) c->v2_off_frames = 0xFFFFFFFFu;
                 ++c->n_redone;
                 redone = true;
+                bool settled = false;
+                if (redo_in_measured_box(c, h0)) {            // (a box miss and nothing else: the same path, in a box that fits)
+                    HIP_TRY(c, hipEventSynchronize(c->ev_done));
+                    c->in_flight.store(false);
+                    const CmFrameState& h1 = *c->h_state;     // (the record the redone frame has written by now)
+                    settled = !h1.outside && !h1.err;
+                    if (h1.outside) c->pred_ok = false;
+                }
+                if (!settled) {                               // every other cause, or a second hand-back: the general path
                 c->prof_used = 0;
                 c->last_v2 = false;
                 c->last_predicted = false;
@@ -984,6 +1024,7 @@ int wait_frame(cm_ctx* c, cm_result* res) {
                 }
                 HIP_TRY(c, hipEventSynchronize(c->ev_done));
                 c->in_flight.store(false);
+                }
                 r.n_sensors = c->n_sensors_used;
                 r.n_in = c->n_in;
             }

@@ -301,6 +301,49 @@ __device__ unsigned long long g_phase[4096 * 16];
 #define PH_START() do {} while (0)
 #define PH(k) do {} while (0)
 #endif
+// The exact bounds of the frame's valid points from k2_hist0's per-tile records (min xyz, max xyz, count): one workgroup,
+// s_f = CM2_WAVES x 8 floats of LDS; writes st->min_p / max_p / n_valid_k0.
+__device__ __forceinline__ void fold_bounds(float* s_f, CmFrameState* __restrict__ st, const float* __restrict__ records,
+                                            uint32_t n_records) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float inf = __uint_as_float(0x7F800000u);
+    float v[6] = {inf, inf, inf, -inf, -inf, -inf};
+    uint32_t cnt = 0;
+    for (uint32_t r = threadIdx.x; r < n_records; r += CM2_BLOCK) {
+        const float4 lo = *reinterpret_cast<const float4*>(records + static_cast<size_t>(r) * 8);
+        const float4 hi = *reinterpret_cast<const float4*>(records + static_cast<size_t>(r) * 8 + 4);
+        v[0] = fminf(v[0], lo.x); v[1] = fminf(v[1], lo.y); v[2] = fminf(v[2], lo.z);
+        v[3] = fmaxf(v[3], lo.w); v[4] = fmaxf(v[4], hi.x); v[5] = fmaxf(v[5], hi.y);
+        cnt += __float_as_uint(hi.z);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] = fminf(v[k], __shfl_xor(v[k], d));
+#pragma unroll
+        for (int k = 3; k < 6; ++k) v[k] = fmaxf(v[k], __shfl_xor(v[k], d));
+        cnt += __shfl_xor(cnt, d);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s_f[w * 8 + k] = v[k];
+        s_f[w * 8 + 6] = __uint_as_float(cnt);
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const int k = threadIdx.x;
+        if (k < 6) {
+            float r = s_f[k];
+            for (int q = 1; q < CM2_WAVES; ++q) r = (k < 3) ? fminf(r, s_f[q * 8 + k]) : fmaxf(r, s_f[q * 8 + k]);
+            if (k < 3) st->min_p[k] = r; else st->max_p[k - 3] = r;
+        } else {
+            uint32_t c = 0;
+            for (int q = 0; q < CM2_WAVES; ++q) c += __float_as_uint(s_f[q * 8 + 6]);
+            st->n_valid_k0 = c;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k2_scatter: stable scatter of one 4096-record tile by one 8-bit digit; the record itself moves.
 // FIRST: reads the raw sensor points (transform + crop once more, dropping invalid slots: this is
@@ -338,7 +381,13 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __r
     __shared__ uint16_t s_dbase[CM_RADIX];
     __shared__ uint32_t lds[CM2_WAVES];
     __shared__ uint32_t s_tile_valid;
-    if (st->status != CM_DEV_OK || st->outside) return;
+    if (st->status != CM_DEV_OK) return;
+    if (st->outside) {
+        // A point left the predicted box: the frame is handed back — with the cloud's exact bounds, which k2_hist0's records
+        // hold all the same, so that the host can redo it in a box that fits (cm_api.cpp wait_frame) instead of measuring again.
+        if (FIRST && fold && blockIdx.x == 0) fold_bounds(reinterpret_cast<float*>(whist), st, records, n_records);
+        return;
+    }
     PH_START();
     uint32_t tile = blockIdx.x;
     {
@@ -579,43 +628,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __r
     // The exact bounds of the cloud (pcl::getMinMax3D) for the result and for the next frame's box.
     if (FIRST && fold && tile == 0) {
         __syncthreads();
-        float* s_f = reinterpret_cast<float*>(whist);         // [CM2_WAVES][8]
-        const float inf = __uint_as_float(0x7F800000u);
-        float v[6] = {inf, inf, inf, -inf, -inf, -inf};
-        uint32_t cnt = 0;
-        for (uint32_t r = threadIdx.x; r < n_records; r += CM2_BLOCK) {
-            const float4 lo = *reinterpret_cast<const float4*>(records + static_cast<size_t>(r) * 8);
-            const float4 hi = *reinterpret_cast<const float4*>(records + static_cast<size_t>(r) * 8 + 4);
-            v[0] = fminf(v[0], lo.x); v[1] = fminf(v[1], lo.y); v[2] = fminf(v[2], lo.z);
-            v[3] = fmaxf(v[3], lo.w); v[4] = fmaxf(v[4], hi.x); v[5] = fmaxf(v[5], hi.y);
-            cnt += __float_as_uint(hi.z);
-        }
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) v[k] = fminf(v[k], __shfl_xor(v[k], d));
-#pragma unroll
-            for (int k = 3; k < 6; ++k) v[k] = fmaxf(v[k], __shfl_xor(v[k], d));
-            cnt += __shfl_xor(cnt, d);
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) s_f[w * 8 + k] = v[k];
-            s_f[w * 8 + 6] = __uint_as_float(cnt);
-        }
-        __syncthreads();
-        if (threadIdx.x < 7) {
-            const int k = threadIdx.x;
-            if (k < 6) {
-                float r = s_f[k];
-                for (int q = 1; q < CM2_WAVES; ++q) r = (k < 3) ? fminf(r, s_f[q * 8 + k]) : fmaxf(r, s_f[q * 8 + k]);
-                if (k < 3) st->min_p[k] = r; else st->max_p[k - 3] = r;
-            } else {
-                uint32_t c = 0;
-                for (int q = 0; q < CM2_WAVES; ++q) c += __float_as_uint(s_f[q * 8 + 6]);
-                st->n_valid_k0 = c;
-            }
-        }
+        fold_bounds(reinterpret_cast<float*>(whist), st, records, n_records);
     }
 }
 

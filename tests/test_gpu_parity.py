@@ -654,8 +654,8 @@ def test_crop_heavy_frames_pack_the_survivors(sort_path, outlier):
 
 def test_predicted_box_miss_is_redone_and_learned(sort_path):
     """No crop box: the bucket path sorts in the previous frame's bounds plus a margin. A frame whose
-    cloud leaves that box is found out on the device, redone by the general path (same answer), and
-    the box follows."""
+    cloud leaves that box is found out on the device and redone at once — on the bucket path again, in a
+    box around the exact bounds the failed attempt measured (same answer) — and the box follows."""
     rng = np.random.default_rng(5)
     near = [xyzi_cloud(rng.uniform(-5, 5, (40_000, 3)), rng.uniform(0, 100, 40_000))]
     far = [xyzi_cloud(rng.uniform(-40, 60, (40_000, 3)), rng.uniform(0, 100, 40_000))]
@@ -675,7 +675,7 @@ def test_predicted_box_miss_is_redone_and_learned(sort_path):
         assert flags == [0] * 5
     else:
         bp = BUCKET | PREDICTED
-        assert flags == [bp, bp, REDONE, bp, bp]        # the far cloud leaves the box once; the near one fits the wider box
+        assert flags == [bp, bp, bp | REDONE, bp, bp]   # the far cloud leaves the box once; the near one fits the wider box
 
 
 def test_bucket_too_large_for_lds_is_redone(sort_path):
