@@ -572,7 +572,9 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
         cmk2_scatter(st, pass == 0, c->d_frame, c->d_tiles, state, in, out, c->dig, c->hist, grp, big ? c->totals : nullptr,
                      low_bits + 8 * pass, pass + 1 < n_global ? low_bits + 8 * (pass + 1) : 32u, nt, n_groups,
                      f.n_padded, c->records, nt, predicted ? 1 : 0, mask, 0, (pack && pass == 0) ? c->rec_b : nullptr, c->wave_cnt,
-                     (c->debug_misrank && pass + 1 == n_global) ? 1 : 0, c->d_tile_kept);
+                     (c->debug_misrank && pass + 1 == n_global) ? 1 : 0, c->d_tile_kept,
+                     // (fewer than a quarter of the points survived the last frame's crop: eight tiles per workgroup)
+                     pack && pass == 0 && !c->debug_misrank && 4ull * c->last_n_merged < c->n_in);
     }
     const void* rec_sorted = ((n_global - 1) & 1u) ? c->rec_b : c->rec_a;
     c->last_k3 = c->finish_mode != 2;

@@ -58,7 +58,7 @@ void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, const CmTileD
                   uint32_t shift, uint32_t next_shift, uint32_t n_tiles, uint32_t n_groups, uint32_t n_padded,
                   const float* records, uint32_t n_records, int fold, const unsigned char* mask, int use_cell = 0,
                   const void* compact_in = nullptr, const uint32_t* wave_cnt = nullptr, int debug_swap = 0,
-                  uint32_t* tile_kept = nullptr);
+                  uint32_t* tile_kept = nullptr, bool sparse = false);   // sparse: k2_scatter_sparse (first pass over packed survivors)
 void cmk2_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next, uint32_t* host_state,
                 const void* rec, unsigned long long* tile_state, uint32_t* ticket, void* out, uint32_t* out_key,
                 uint32_t* out_cnt, void* partial_out, uint32_t low_bits, uint32_t n_padded);

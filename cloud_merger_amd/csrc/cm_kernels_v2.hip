@@ -633,6 +633,113 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __r
 }
 
 // ------------------------------------------------------------------------------------------------
+// k2_scatter_sparse: the first scatter of a frame whose crop box drops most of its points, from the records k2_hist0<PACK>
+// left packed per wave. k2_scatter<true> gives every 4096-slot tile a workgroup of its own — offsets prologue, ranking,
+// two staging rounds — for what may be a hundred survivors (cfg3: 3906 workgroups, 38 us for 10 MB of records). Here a
+// workgroup takes EIGHT consecutive tiles: one prologue for all of them (the offsets of tile T + k are those of tile T
+// plus the counts of the tiles between), then wave k carries tile T + k's survivors — chunk by chunk in (wave, slot)
+// order, ranked by returning LDS adds on counters of its own, written straight from registers (few records: no
+// staging) — without another workgroup barrier. Same positions as k2_scatter<true>, record for record.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(CM2_BLOCK) void k2_scatter_sparse(const CmFrameDev* __restrict__ fd, CmFrameState* __restrict__ st,
+                                                               const float4* __restrict__ compact_in,
+                                                               const uint32_t* __restrict__ wave_cnt,
+                                                               float4* __restrict__ rec_out, unsigned char* __restrict__ dig_out,
+                                                               const uint32_t* __restrict__ hist, const uint32_t* __restrict__ grp,
+                                                               const uint32_t* __restrict__ totals, uint32_t shift,
+                                                               uint32_t next_shift, uint32_t n_groups, uint32_t n_tiles,
+                                                               int use_cell, uint32_t* __restrict__ tile_kept) {
+    static_assert(CM2_WAVES == 8 && CM_GROUP % CM2_WAVES == 0, "eight tiles of one group per workgroup");
+    __shared__ uint32_t offs[CM2_WAVES][CM_RADIX];        // first position of digit d among tile T + k's records
+    __shared__ uint32_t wcnt[CM2_WAVES][CM_RADIX / 2];    // a wave's digit counters, two 16-bit counters per word
+    __shared__ uint32_t part[CM_RADIX];
+    __shared__ uint32_t lds[CM2_WAVES];
+    if (st->status != CM_DEV_OK || st->outside) return;
+    const uint32_t T = blockIdx.x * CM2_WAVES;
+    const BoxGrid b = box_grid_of(fd, use_cell);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t grp_id = T / CM_GROUP;
+    const uint32_t d = threadIdx.x & (CM_RADIX - 1);
+    uint32_t before = 0, my_total = 0;
+    if (threadIdx.x < CM_RADIX) {                          // records of digit d in the groups before this one (see k2_scatter)
+        if (totals) {
+            my_total = totals[d];
+            before = grp[static_cast<size_t>(grp_id) * CM_RADIX + d];
+        } else {
+            for (uint32_t g = 0; g < n_groups; g += 16) {
+                uint32_t v[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) v[q] = (g + q < n_groups) ? grp[static_cast<size_t>(g + q) * CM_RADIX + d] : 0u;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { my_total += v[q]; before += (g + q < grp_id) ? v[q] : 0u; }
+            }
+        }
+    } else {                                               // ... and in the tiles of this group before tile T
+        for (uint32_t t = grp_id * CM_GROUP; t < T; t += 16) {
+            uint32_t v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = (t + q < T) ? hist[static_cast<size_t>(t + q) * CM_RADIX + d] : 0u;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) before += v[q];
+        }
+        part[d] = before;
+    }
+    (&wcnt[0][0])[threadIdx.x] = 0;                        // (CM2_WAVES * CM_RADIX / 2 == 2 * CM2_BLOCK words)
+    (&wcnt[0][0])[CM2_BLOCK + threadIdx.x] = 0;
+    static_assert(CM2_WAVES * (CM_RADIX / 2) == 2 * CM2_BLOCK, "counter words per thread");
+    uint32_t gtot;
+    const uint32_t gbase = block_excl_scan_w<CM2_WAVES>(my_total, lds, &gtot);     // (its barriers publish part[])
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->n_valid = gtot;
+    if (threadIdx.x < CM_RADIX) {
+        uint32_t hv[CM2_WAVES];
+#pragma unroll
+        for (int k = 0; k < CM2_WAVES; ++k) hv[k] = (T + k < n_tiles) ? hist[static_cast<size_t>(T + k) * CM_RADIX + d] : 0u;
+        uint32_t run = gbase + before + part[d];
+#pragma unroll
+        for (int k = 0; k < CM2_WAVES; ++k) { offs[k][d] = run; run += hv[k]; }
+    }
+    __syncthreads();
+    const uint32_t tile = T + w;
+    if (tile >= n_tiles) return;
+    uint32_t cw[CM2_WAVES], total = 0, most = 0;
+#pragma unroll
+    for (int q = 0; q < CM2_WAVES; ++q) {
+        cw[q] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(wave_cnt[tile * CM2_WAVES + q])));
+        total += cw[q];
+        most = max(most, cw[q]);
+    }
+    const float4* __restrict__ src = compact_in + static_cast<size_t>(tile) * CM_TILE;
+    // one record of one chunk: ranked among the tile's records of its digit by a returning LDS add (the chunks the eight
+    // waves of k2_hist0 packed are taken in their order, a chunk's records 64 at a time: the order k2_scatter ranks in)
+    auto place = [&](const float4& r4, bool has) {
+        const uint32_t k = key_of(b, r4);
+        const uint32_t dg = (k >> shift) & (CM_RADIX - 1), sh = (dg & 1u) * 16u;
+        // (a lane without a record adds nothing, to a word of its own: see k2_scatter)
+        const uint32_t old = atomicAdd(&wcnt[w][has ? dg >> 1 : static_cast<uint32_t>(lane)], (has ? 1u : 0u) << sh);
+        if (has) {
+            const uint32_t pos = offs[w][dg] + ((old >> sh) & 0xFFFFu);
+            rec_out[pos] = r4;
+            if (next_shift < 32u) dig_out[pos] = static_cast<unsigned char>((k >> next_shift) & 0xFFu);
+        }
+    };
+    if (most <= 64u) {                                     // the usual case: every chunk is one load — all eight in flight at once
+        float4 r4[CM2_WAVES];
+#pragma unroll
+        for (int q = 0; q < CM2_WAVES; ++q)
+            r4[q] = src[q * (64 * CM2_ITEMS) + (static_cast<uint32_t>(lane) < cw[q] ? lane : 0)];
+#pragma unroll
+        for (int q = 0; q < CM2_WAVES; ++q) place(r4[q], static_cast<uint32_t>(lane) < cw[q]);
+    } else {
+        for (int q = 0; q < CM2_WAVES; ++q)
+            for (uint32_t i0 = 0; i0 < cw[q]; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                place(src[q * (64 * CM2_ITEMS) + (i < cw[q] ? i : 0u)], i < cw[q]);
+            }
+    }
+    if (tile_kept && lane == 0) tile_kept[tile] = total;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k2_local: the finish. `rec` is grouped by H = key >> low_bits (ascending). Workgroup t owns the
 // buckets (runs of equal H) that START inside records [t*4096, (t+1)*4096): it skips the head of
 // its tile that continues the previous workgroup's last bucket and reads past its end until its
@@ -1046,9 +1153,15 @@ void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, const CmTileD
                   unsigned char* dig_out, const uint32_t* hist, const uint32_t* grp, const uint32_t* totals,
                   uint32_t shift, uint32_t next_shift, uint32_t n_tiles, uint32_t n_groups, uint32_t n_padded,
                   const float* records, uint32_t n_records, int fold, const unsigned char* mask, int use_cell,
-                  const void* compact_in, const uint32_t* wave_cnt, int debug_swap, uint32_t* tile_kept) {
+                  const void* compact_in, const uint32_t* wave_cnt, int debug_swap, uint32_t* tile_kept, bool sparse) {
     const float4* in = reinterpret_cast<const float4*>(rec_in);
     float4* o = reinterpret_cast<float4*>(rec_out);
+    if (first && compact_in && sparse) {
+        hipLaunchKernelGGL(k2_scatter_sparse, dim3((n_tiles + CM2_WAVES - 1) / CM2_WAVES), dim3(CM2_BLOCK), 0, s, fd, st,
+                           reinterpret_cast<const float4*>(compact_in), wave_cnt, o, dig_out, hist, grp, totals, shift,
+                           next_shift, n_groups, n_tiles, use_cell, tile_kept);
+        return;
+    }
     if (first)
         hipLaunchKernelGGL(k2_scatter<true>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, in, o, dig_out, hist, grp,
                            totals, shift, next_shift, n_groups, n_padded, records, n_records, fold, mask, use_cell,
