@@ -148,6 +148,7 @@ struct cm_ctx {
     uint32_t pre_bucket_backoff = 16;
     bool pre_bucket = false;             // this frame's outlier stage may sort with the bucket kernels
     bool last_packed = false;            // the voxel stage's k2_hist0 packed the survivors (CM_PATH_PACKED)
+    uint32_t grid_shrink_off = 0;        // frames for which the kernels behind pass 0 get whole grids again (after CM_DEV_ERR_GRID)
     bool last_v2 = false, last_predicted = false, last_k3 = false;
     bool post_bucket = false;            // the frame's pre-stages (ground / outlier removal) run first, then the bucket path
     uint32_t post_g = 0, post_low = 0;
@@ -551,7 +552,6 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
     const uint32_t n_groups = (nt + CM_GROUP - 1) / CM_GROUP;
     const uint32_t gw = n_groups * CM_RADIX;
     const size_t gstride = static_cast<size_t>(c->cap_groups) * CM_RADIX;
-    const bool big = n_groups > CM_DIRECT_GROUPS;
     uint32_t* grp0 = c->grp + gstride * (c->frame_seq & 1u);
     uint32_t* grp0_next = c->grp + gstride * ((c->frame_seq & 1u) ^ 1u);
     ++c->frame_seq;
@@ -562,15 +562,29 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
     cmk2_hist0(st, f, c->d_frame, c->d_tiles, do_setup, state, c->hist, grp0, grp0_next, c->grp + 2 * gstride, gw, static_cast<uint32_t>(gstride),
                c->tile_state, f.n_padded / 1024 + 2, c->records, grid_mode, predicted ? 1 : 0, low_bits, n_global, nt, mask,
                st_outlier, 0, pack ? c->rec_b : nullptr, c->wave_cnt);
+    // The passes behind the first, and the finish, work on the records pass 0 kept. When a crop box dropped most points of
+    // the last frame their grids are sized for what that frame kept (+ 50 % + two tiles), not for the padded frame — most of
+    // those workgroups would only find out that they have nothing to do (cfg3: 3906 / 7812 of them for 157 / 313 tiles of
+    // records). Verified on the device: k3_compact raises CM_DEV_ERR_GRID when the records need more, the frame is redone
+    // and the next frames use whole grids again.
+    uint32_t nt_later = nt;
+    if (mode == 0 && !predicted && f.crop_enable && c->last_n_merged && !c->grid_shrink_off && c->finish_mode != 2) {
+        const uint64_t est = static_cast<uint64_t>(c->last_n_merged) + c->last_n_merged / 2 + 2 * CM_TILE;
+        nt_later = static_cast<uint32_t>(std::min<uint64_t>(nt, (est + CM_TILE - 1) / CM_TILE));
+    }
+    if (c->grid_shrink_off) --c->grid_shrink_off;
+    const uint32_t n_groups_later = (nt_later + CM_GROUP - 1) / CM_GROUP;
     for (uint32_t pass = 0; pass < n_global; ++pass) {
         uint32_t* grp = pass == 0 ? grp0 : c->grp + 2 * gstride + static_cast<size_t>(pass - 1) * gw;
-        if (pass > 0) { prof_mark(c, "k2_hist"); cmk2_hist(st, state, c->dig, c->hist, grp, nt); }
-        if (big) { prof_mark(c, "k_gscan"); cmk_gscan(st, state, grp, c->totals, pass, n_groups); }
+        const uint32_t nt_p = pass == 0 ? nt : nt_later, n_groups_p = pass == 0 ? n_groups : n_groups_later;
+        const bool big_p = n_groups_p > CM_DIRECT_GROUPS;
+        if (pass > 0) { prof_mark(c, "k2_hist"); cmk2_hist(st, state, c->dig, c->hist, grp, nt_p); }
+        if (big_p) { prof_mark(c, "k_gscan"); cmk_gscan(st, state, grp, c->totals, pass, n_groups_p); }
         prof_mark(c, "k2_scatter");
         const void* in = (pass & 1u) ? c->rec_a : c->rec_b;
         void* out = (pass & 1u) ? c->rec_b : c->rec_a;
-        cmk2_scatter(st, pass == 0, c->d_frame, c->d_tiles, state, in, out, c->dig, c->hist, grp, big ? c->totals : nullptr,
-                     low_bits + 8 * pass, pass + 1 < n_global ? low_bits + 8 * (pass + 1) : 32u, nt, n_groups,
+        cmk2_scatter(st, pass == 0, c->d_frame, c->d_tiles, state, in, out, c->dig, c->hist, grp, big_p ? c->totals : nullptr,
+                     low_bits + 8 * pass, pass + 1 < n_global ? low_bits + 8 * (pass + 1) : 32u, nt_p, n_groups_p,
                      f.n_padded, c->records, nt, predicted ? 1 : 0, mask, 0, (pack && pass == 0) ? c->rec_b : nullptr, c->wave_cnt,
                      (c->debug_misrank && pass + 1 == n_global) ? 1 : 0, c->d_tile_kept,
                      // (fewer than a quarter of the points survived the last frame's crop: eight tiles per workgroup)
@@ -591,10 +605,10 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
         uint32_t* skey = c->out_key ? c->keys_a : nullptr;
         prof_mark(c, "k3_local");
         cmk3_local(st, c->d_frame, state, c->h_state_dev, rec_sorted, c->tile_state, grp_cnt, stage, skey, c->vals_a, mode == 1,
-                   low_bits, f.n_padded);
+                   low_bits, nt_later * CM_TILE);
         prof_mark(c, "k3_compact");
         cmk3_compact(st, state, state_next, c->h_state_dev, c->tile_state, grp_cnt, stage, skey, c->vals_a,
-                     mode == 1 ? c->partial : c->out, c->out_key, c->out_cnt, mode == 1, f.n_padded);
+                     mode == 1 ? c->partial : c->out, c->out_key, c->out_cnt, mode == 1, nt_later * CM_TILE);
     } else {
         prof_mark(c, "k2_local");
         cmk2_local(st, c->d_frame, state, state_next, c->h_state_dev, rec_sorted,
@@ -984,7 +998,8 @@ int wait_frame(cm_ctx* c, cm_result* res) {
             // classic path redoes it (the sensors' clouds are still in place) and the cause is dealt with.
             const CmFrameState& h0 = *c->h_state;
             if (h0.outside || h0.err == CM_DEV_ERR_BUCKET || h0.err == CM_DEV_ERR_BUCKET_PRE || h0.err == CM_DEV_ERR_LOOKBACK ||
-                h0.err == CM_DEV_ERR_UNSORTED) {
+                h0.err == CM_DEV_ERR_UNSORTED || h0.err == CM_DEV_ERR_GRID) {
+                if (h0.err == CM_DEV_ERR_GRID) c->grid_shrink_off = 64;   // more records than the last frame promised: whole grids for a while
                 if (h0.outside) c->pred_ok = false;
                 // The finish found records out of bucket order: a global pass mis-ranked. Stop trusting lane-ordered LDS adds
                 // on this device (the general path then ranks by ballots, and the bucket path, which needs them, stays off).

@@ -137,6 +137,7 @@ struct CmFrameState {
 #define CM_DEV_ERR_LOOKBACK 3u   // ... a workgroup waited too long for its predecessors' counts
 #define CM_DEV_ERR_BUCKET 4u     // ... a bucket did not fit the local finish's LDS capacity
 #define CM_DEV_ERR_BUCKET_PRE 5u // ... the same in the outlier stage's sort (a radius cell with thousands of points)
+#define CM_DEV_ERR_GRID 6u       // ... the kernels behind pass 0 were launched with fewer workgroups than the kept records need
 #define CM_DEV_OUTLIER_GRID 3   // the radius grid of the outlier stage does not fit (rows or 32-bit index)
 #define CM_DEV_ABORTED 4        // a stage gave up (CmFrameState.err says why): every later kernel of the frame leaves at once —
                                 // what the stage left behind (half-sorted keys, unwritten records) must not be indexed with

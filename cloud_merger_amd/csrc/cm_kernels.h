@@ -52,7 +52,7 @@ void cmk2_hist0(hipStream_t s, const CmFrameDev& f, CmFrameDev* fd, CmTileDev* t
                 uint32_t shift0, uint32_t n_global_passes, uint32_t n_tiles, const unsigned char* mask,
                 const CmFrameState* st_outlier, int use_cell = 0, void* compact_out = nullptr, uint32_t* wave_cnt = nullptr);
 void cmk2_hist(hipStream_t s, const CmFrameState* st, const unsigned char* dig, uint32_t* hist, uint32_t* grp,
-               uint32_t n_tiles);
+               uint32_t n_tiles);                          // n_tiles: the grid (tiles of the records pass 0 kept: may be fewer than the frame's)
 void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, const CmTileDev* tiles, CmFrameState* st, const void* rec_in, void* rec_out,
                   unsigned char* dig_out, const uint32_t* hist, const uint32_t* grp, const uint32_t* totals,
                   uint32_t shift, uint32_t next_shift, uint32_t n_tiles, uint32_t n_groups, uint32_t n_padded,
@@ -70,7 +70,7 @@ void cmk2_local_sort(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint
 // tile_info: one uint2 per 2048-record tile; grp_cnt: one zeroed word per 64 tiles; stage: 16 B (32 B: partial) per record slot
 void cmk3_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* host_state, const void* rec, void* tile_info,
                 uint32_t* grp_cnt, void* stage, uint32_t* stage_key, uint32_t* stage_cnt, bool partial, uint32_t low_bits,
-                uint32_t n_padded);
+                uint32_t n_slots);                         // n_slots / 2048 workgroups (n_padded, or what the records are expected to need)
 void cmk3_compact(hipStream_t s, const CmFrameState* st, CmFrameState* st_next, uint32_t* host_state, const void* tile_info,
                   const uint32_t* grp_cnt, const void* stage, const uint32_t* stage_key, const uint32_t* stage_cnt, void* out,
                   uint32_t* out_key, uint32_t* out_cnt, bool partial, uint32_t n_padded);

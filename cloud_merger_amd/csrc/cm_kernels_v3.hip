@@ -516,6 +516,9 @@ __global__ __launch_bounds__(256) void k3_compact(const CmFrameState* __restrict
     }
     const uint32_t n_lt = (n + LT - 1) / LT;
     const uint32_t tile = blockIdx.x;
+    // The kernels behind pass 0 may have been launched for fewer records than the frame's slots (a crop box that dropped
+    // most points of the last frame: cm_api.cpp launch_bucket): more records than that, and the frame is handed back.
+    if (tile == 0 && threadIdx.x == 0 && n_lt > gridDim.x) host_state[offsetof(CmFrameState, err) / 4] = CM_DEV_ERR_GRID;
     if (tile >= n_lt) return;
     const uint2 info = tile_info[tile];
     if (info.y == 0 && tile != n_lt - 1) return;               // nothing to move (the last tile still reports)

@@ -634,7 +634,7 @@ def test_crop_heavy_frames_pack_the_survivors(sort_path, outlier):
         params.outlier_radius, params.outlier_min_neighbors = 0.3, 1
     wide = MergeParams(leaf=params.leaf, min_points_per_voxel=0, crop_min=(-45.0, -45.0, -3.0), crop_max=(45.0, 45.0, 7.0))
     with capi.CloudMerger(max_points_total=720_000, max_sensors=6, flags=capi.FLAG_OCCUPANCY) as cm:
-        flags = []
+        flags, redone = [], []
         for p in (params, params, params, wide, wide, params):
             st, merged, out, rep = oracle.merge_voxelize(sensors, p, threads=4, stable=True)
             g = run_gpu(sensors, p, cm=cm)
@@ -645,9 +645,14 @@ def test_crop_heavy_frames_pack_the_survivors(sort_path, outlier):
             if g["res"].path_flags & BUCKET:
                 assert_bucket_centroids(g["out"], xyzi_of(out), rep.counts)
             flags.append(bool(g["res"].path_flags & PACKED))
+            redone.append(bool(g["res"].path_flags & REDONE))
         assert rep.n_merged * 2 < sum(s.n for s in sensors)
     if g["res"].path_flags & BUCKET:
-        assert flags == [False, True, True, True, False, False]     # decided from the frame before
+        # packing is decided from the frame before; the first wide frame keeps far more records than the narrow one before it
+        # promised — the kernels behind the first pass were launched for those (CM_DEV_ERR_GRID): handed back and redone
+        assert flags[:3] == [False, True, True] and flags[4:] == [False, False]
+        assert (flags[3] and not redone[3]) or (redone[3] and not flags[3])
+        assert not any(redone[:3]) and not any(redone[4:])
     else:
         assert not any(flags)
 
@@ -911,3 +916,30 @@ def test_async_submit_result_and_frame_stats(sort_path):
     finally:
         for h in holders + [dst]:
             h.free()
+
+
+def test_more_survivors_than_the_last_frame_promised(sort_path):
+    """In a crop box that dropped most points of the last frame, the kernels behind the first pass are launched for what
+    that frame kept (+ 50 %): a frame that keeps several times as much is noticed on the device (k3_compact), handed back
+    and redone; the frames after it get whole grids again."""
+    rng = np.random.default_rng(31)
+    box = dict(crop_min=(-2.0, -2.0, -1.0), crop_max=(2.0, 2.0, 1.0))
+    params = MergeParams(leaf=(0.05,) * 3, min_points_per_voxel=0, **box)
+    n = 120_000
+    few = rng.uniform(-20, 20, (n, 3)).astype(np.float32)                     # ~ 0.05 % inside the box
+    few[:3000] = rng.uniform(-1, 1, (3000, 3))
+    many = few.copy()
+    many[:60_000] = rng.uniform(-1, 1, (60_000, 3))                            # twenty times as many survivors
+    with capi.CloudMerger(max_points_total=n, max_sensors=1, flags=capi.FLAG_OCCUPANCY) as cm:
+        flags = []
+        for xyz in (few, few, many, many, few):
+            sensors = [xyzi_cloud(xyz, np.ones(n, np.float32))]
+            g = run_gpu(sensors, params, want_merged=False, cm=cm)
+            st, _, out, rep = oracle.merge_voxelize(sensors, params, stable=True)
+            assert g["res"].status == st == capi.OK and g["res"].n_out == rep.n_out
+            assert np.array_equal(g["cells"], rep.cells) and np.array_equal(g["counts"], rep.counts)
+            assert_centroids_close(g["out"], xyzi_of(out))
+            flags.append(g["res"].path_flags & (BUCKET | REDONE))
+            lds_rank = g["res"].path_flags & 1
+    if sort_path == "auto" and lds_rank:
+        assert flags[0] == BUCKET and flags[1] == BUCKET and flags[2] == REDONE and flags[3] == BUCKET and flags[4] == BUCKET
