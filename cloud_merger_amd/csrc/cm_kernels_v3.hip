@@ -372,6 +372,7 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
                 ++cn;
             }
         }
+        PH3(3);
         if (on) {
             // the last voxel may go on past the block: four positions at a time, loads first — up to CM3_EXT_SEQ positions
             // one after the other (stable order, bit for bit pcl's sum); a voxel longer than that is finished by a wave
@@ -414,10 +415,11 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
             }
         }
 
+        PH3(4);
         // ---- long voxels. A wave sums 64 positions per chunk, eight chunks (512 positions) per step: every record of a step
         // asked for at once, a chunk's sum formed in a fixed tree order and added to the running sum chunk after chunk:
         // deterministic, within 1e-4 m of pcl's one-after-the-other sum (closer to the exact mean, in fact), not
-        // bit-identical to it. Normally wave w takes jobs w, w + LWAVES, ... whole; with fewer jobs than waves in a tile
+        // bit-identical to it. Normally wave w takes jobs w, w + LWAVES, ... (first chunks four jobs at a time); with fewer jobs than waves in a tile
         // whose voxels average 512 points or more (coarse grids: a tile's records are a voxel or two of thousands of
         // points, and the tiles behind it have nothing of their own to do) all waves share every job — wave w takes the
         // steps w, w + LWAVES, ... of it — and their partial sums are added in wave order.
@@ -425,8 +427,68 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
         const uint32_t njobs = SCAL(s_njobs);
         const bool coop = !(njobs >= static_cast<uint32_t>(LWAVES) || m < 512u * max(c_t, 1u));   // (uniform)
         Job3* part = jobs + 64;                                // (coop: fewer than LWAVES jobs — room for the waves' partial sums)
+        // one chunk: the 64 positions from p on that belong to the run of jkey (in: which lanes hold one of its records)
+        auto load_chunk = [&](uint32_t p, uint32_t jkey, float4& r4, bool& in) {
+            const uint32_t q = p + lane;
+            in = false;
+            r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (L == 0) {                                      // sorted position q is record base + a + q, in LDS or not
+                const unsigned long long idx = static_cast<unsigned long long>(base) + a + q;
+                if (idx < n) { r4 = rec[idx]; in = true; }
+            } else if (q < m) {
+                const uint32_t sl_ = si[q];
+                if (sk[sl_] == jkey) { r4 = rec[base + sl_]; in = true; }
+            }
+        };
+        // Opening round: most long voxels are not that long (dense ground cells: tens of points), and a wave that takes
+        // its jobs one after the other pays a round trip to L2 for each. The first chunk of four jobs is asked for
+        // together; a job that ends inside it is finished here, the others go on below from their second chunk (the
+        // chunks of a job are added in the same order either way: same sums, bit for bit).
+        constexpr uint32_t JOB_DONE = 0xFFFFFFFFu;
+        if (!coop && L != 0) {                                 // (L == 0: dense frames, jobs of thousands of points — no short ones to gain on)
+            constexpr int JB = 4;
+            for (uint32_t j0 = w; j0 < njobs; j0 += LWAVES * JB) {
+                float4 r4[JB];
+                bool in[JB];
+                uint32_t jk[JB];
+#pragma unroll
+                for (int u = 0; u < JB; ++u) {
+                    const uint32_t jn = j0 + u * LWAVES;
+                    in[u] = false; r4[u] = make_float4(0.f, 0.f, 0.f, 0.f); jk[u] = 0;
+                    if (jn < njobs) {                          // (uniform)
+                        jk[u] = SCAL(jobs[jn].key);
+                        const uint32_t q = SCAL(jobs[jn].p) + lane;
+                        if (q < m) {
+                            const uint32_t sl_ = si[q];
+                            if (sk[sl_] == jk[u]) { r4[u] = rec[base + sl_]; in[u] = true; }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < JB; ++u) {
+                    const uint32_t jn = j0 + u * LWAVES;
+                    if (jn >= njobs) break;                    // (uniform)
+                    const unsigned long long bal = __ballot(in[u]);
+                    const Job3 jb = jobs[jn];
+                    const float ax = __fadd_rn(jb.sx, wave_sum_f32_fixed(r4[u].x)), ay = __fadd_rn(jb.sy, wave_sum_f32_fixed(r4[u].y));
+                    const float az = __fadd_rn(jb.sz, wave_sum_f32_fixed(r4[u].z)), aw = __fadd_rn(jb.sw, wave_sum_f32_fixed(r4[u].w));
+                    const uint32_t cnj = SCAL(jb.cnt) + static_cast<uint32_t>(__popcll(bal));
+                    if (lane == 0) {
+                        if (bal != ~0ull) {                    // the run ended inside this chunk: done
+                            emit(SCAL(jb.kid), jk[u], ax, ay, az, aw, cnj);
+                            jobs[jn].p = JOB_DONE;
+                        } else {
+                            Job3 nx = jb;
+                            nx.p = jb.p + 64u; nx.cnt = cnj; nx.sx = ax; nx.sy = ay; nx.sz = az; nx.sw = aw;
+                            jobs[jn] = nx;
+                        }
+                    }
+                }
+            }
+        }
         for (uint32_t jn = coop ? 0u : w; jn < njobs; jn += coop ? 1u : static_cast<uint32_t>(LWAVES)) {
             const Job3 jb = jobs[jn];
+            if (SCAL(jb.p) == JOB_DONE) continue;              // (finished in the opening round; uniform)
             const uint32_t jkey = SCAL(jb.key);
             uint32_t p = SCAL(jb.p) + (coop ? w * (64u * 8u) : 0u), cnj = coop ? 0u : SCAL(jb.cnt);
             const uint32_t stride = coop ? LWAVES * 64u * 8u : 64u * 8u;
@@ -437,18 +499,7 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
                 float4 r4[JU];
                 bool in[JU];
 #pragma unroll
-                for (int u = 0; u < JU; ++u) {
-                    const uint32_t q = p + u * 64 + lane;
-                    in[u] = false;
-                    r4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (L == 0) {                              // sorted position q is record base + a + q, in LDS or not
-                        const unsigned long long idx = static_cast<unsigned long long>(base) + a + q;
-                        if (idx < n) { r4[u] = rec[idx]; in[u] = true; }
-                    } else if (q < m) {
-                        const uint32_t sl_ = si[q];
-                        if (sk[sl_] == jkey) { r4[u] = rec[base + sl_]; in[u] = true; }
-                    }
-                }
+                for (int u = 0; u < JU; ++u) load_chunk(p + u * 64, jkey, r4[u], in[u]);
 #pragma unroll
                 for (int u = 0; u < JU; ++u) {
                     if (ended) break;                          // (uniform)
@@ -484,7 +535,7 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
             }
         }
     }
-    PH3(3);
+    PH3(5);
     if (threadIdx.x == 0) {
         tile_info[tile] = make_uint2(a == 0xFFFFFFFFu ? 0u : a, c_t);
         if (c_t) atomicAdd(&grp_cnt[tile >> 6], c_t);
