@@ -32,8 +32,8 @@ HBM_COPY_GBS = 6290.0          # measured float4-copy ceiling, same guide (SURVE
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--stream-frames", type=int, default=6, help="distinct frames of the moving stream (6 x 64 MB of input > 256 MiB)")
     ap.add_argument("--jump-every", type=int, default=64, help="every this many frames one reaches 30 %% further out (0: never)")
     ap.add_argument("--static", action="store_true", help="the round-1 loop: one frame resubmitted every step")
