@@ -943,3 +943,30 @@ def test_more_survivors_than_the_last_frame_promised(sort_path):
             lds_rank = g["res"].path_flags & 1
     if sort_path == "auto" and lds_rank:
         assert flags[0] == BUCKET and flags[1] == BUCKET and flags[2] == REDONE and flags[3] == BUCKET and flags[4] == BUCKET
+
+
+def test_sparse_first_scatter_with_full_chunks(sort_path):
+    """k2_scatter_sparse (fewer than a quarter of the points survived the last frame's crop) also has to carry tiles whose
+    survivors are not a sprinkling: clouds whose first fifth lies inside the box and the rest outside leave whole tiles of
+    survivors (512 per packed chunk: the chunk loop, not the one-load-per-chunk path) beside empty ones."""
+    rng = np.random.default_rng(41)
+    n = 150_000
+    sensors = []
+    for k in range(3):
+        xyz = rng.uniform(-40, 40, (n, 3)).astype(np.float32)
+        xyz[np.abs(xyz).max(axis=1) < 3.0] += 10.0                     # (nobody inside by chance)
+        m = n // 5 + 37 * k
+        xyz[:m] = rng.uniform(-2.9, 2.9, (m, 3))
+        sensors.append(xyzi_cloud(xyz, rng.uniform(0, 255, n), q_xyzw=synth.yaw_quaternion(0.1 * k), t_xyz=(0.0, 0.0, 0.0)))
+    params = MergeParams(leaf=(0.05,) * 3, min_points_per_voxel=2, crop_min=(-2.5, -2.5, -2.5), crop_max=(2.5, 2.5, 2.5))
+    st, merged, out, rep = oracle.merge_voxelize(sensors, params, threads=4, stable=True)
+    assert st == oracle.OK and 4 * rep.n_merged < 3 * n
+    with capi.CloudMerger(max_points_total=3 * n, max_sensors=3, flags=capi.FLAG_OCCUPANCY) as cm:
+        for frame in range(3):
+            g = run_gpu(sensors, params, cm=cm)
+            assert g["res"].status == capi.OK and g["res"].n_out == rep.n_out and g["res"].n_merged == rep.n_merged
+            assert same_bits(g["merged"], xyzi_of(merged))
+            assert np.array_equal(g["cells"], rep.cells) and np.array_equal(g["counts"], rep.counts)
+            assert_centroids_close(g["out"], xyzi_of(out))
+            if g["res"].path_flags & BUCKET:
+                assert bool(g["res"].path_flags & PACKED) == (frame > 0) and not (g["res"].path_flags & REDONE)
