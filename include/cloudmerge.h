@@ -111,8 +111,10 @@ typedef struct cm_result {
                                   packed while counting, so the raw clouds were read once instead of twice */
 #define CM_PATH_SPLIT 32u      /* bucket path, finish by k3_local + k3_compact (tiles stage their centroids, a second launch
                                   packs them: no look-back between tiles); otherwise k2_local */
-#define CM_PATH_REDONE 8u      /* the bucket path gave the frame back (a point outside the predicted box, or a
-                                  bucket too large for LDS) and the general path computed it */
+#define CM_PATH_REDONE 8u      /* the bucket path gave the frame back and it was computed a second time inside cm_wait: after
+                                  a point outside the predicted box on the bucket path again, in a box around the bounds the
+                                  first attempt measured (CM_PATH_BUCKET | CM_PATH_PREDICTED stay set); after a bucket too large
+                                  for LDS, or more survivors of the crop than the last frame promised, on the general path */
 
 #define CM_MAX_STAGES 48
 typedef struct cm_stage_times {
