@@ -175,21 +175,22 @@ __device__ __forceinline__ void load_tile_points(const CmSensorDev& sd, uint32_t
 
 // A point of the two aligned layouts at a 32-bit byte offset from a wave-uniform base (the tile's first point: the
 // offset stays below CM_TILE * 32 bytes), so that the address is scalar base + one VGPR, not a 64-bit multiply-add per load.
-template <int LAYOUT>
+// NT: non-temporal load (the last read of the bytes: do not keep them in the caches).
+template <int LAYOUT, bool NT = false>
 __device__ __forceinline__ Pt load_point_near(const unsigned char* __restrict__ data_generic, uint32_t idx) {
     cm_gptr data = (cm_gptr)data_generic;
     typedef const CM_GLOBAL_AS cm_v4f* f4ptr;
     typedef const CM_GLOBAL_AS float* f1ptr;
     Pt p;
     const uint32_t off = idx * (LAYOUT == CM_LAYOUT_XYZI16 ? 16u : 32u);
-    const cm_v4f v = *(f4ptr)(data + off);
+    const cm_v4f v = NT ? __builtin_nontemporal_load((f4ptr)(data + off)) : *(f4ptr)(data + off);
     p.x = v.x; p.y = v.y; p.z = v.z; p.i = v.w;
     if (LAYOUT == CM_LAYOUT_PCL32) p.i = *(f1ptr)(data + off + 16u);
     return p;
 }
 
 // The same from a tile entry (k_setup): `first` counts from the tile's first point.
-template <int LAYOUT, int N>
+template <int LAYOUT, int N, bool NT = false>
 __device__ __forceinline__ void load_tile_raw(const unsigned char* __restrict__ data, uint32_t n, uint32_t step, uint32_t ox,
                                               uint32_t oy, uint32_t oz, uint32_t oi, uint32_t first, Pt (&p)[N]) {
     const float nan = __uint_as_float(0x7FC00000u);
@@ -197,7 +198,7 @@ __device__ __forceinline__ void load_tile_raw(const unsigned char* __restrict__ 
     for (int r = 0; r < N; ++r) {
         const uint32_t i = first + r * 64;
         if (LAYOUT == CM_LAYOUT_GENERIC) p[r] = load_point(data, LAYOUT, step, ox, oy, oz, oi, i < n ? i : n - 1);
-        else p[r] = load_point_near<LAYOUT>(data, i < n ? i : n - 1);
+        else p[r] = load_point_near<LAYOUT, NT>(data, i < n ? i : n - 1);
     }
 #pragma unroll
     for (int r = 0; r < N; ++r) {
@@ -206,11 +207,11 @@ __device__ __forceinline__ void load_tile_raw(const unsigned char* __restrict__ 
         p[r].i = ok ? p[r].i : 0.f;
     }
 }
-template <int N>
+template <int N, bool NT = false>
 __device__ __forceinline__ void load_tile_te(const CmTileDev& te, const CmSensorDev& sd, uint32_t first, Pt (&p)[N]) {
     const uint32_t layout = te.info >> 8;
-    if (layout == CM_LAYOUT_XYZI16) load_tile_raw<CM_LAYOUT_XYZI16, N>(te.data, te.n_left, 16u, 0u, 4u, 8u, 12u, first, p);
-    else if (layout == CM_LAYOUT_PCL32) load_tile_raw<CM_LAYOUT_PCL32, N>(te.data, te.n_left, 32u, 0u, 4u, 8u, 16u, first, p);
+    if (layout == CM_LAYOUT_XYZI16) load_tile_raw<CM_LAYOUT_XYZI16, N, NT>(te.data, te.n_left, 16u, 0u, 4u, 8u, 12u, first, p);
+    else if (layout == CM_LAYOUT_PCL32) load_tile_raw<CM_LAYOUT_PCL32, N, NT>(te.data, te.n_left, 32u, 0u, 4u, 8u, 16u, first, p);
     else load_tile_raw<CM_LAYOUT_GENERIC, N>(te.data, te.n_left, sd.point_step, sd.off_x, sd.off_y, sd.off_z, sd.off_i, first, p);
 }
 
