@@ -358,7 +358,7 @@ def main():
         s1 = streams[1] if inflight > 1 else torch.cuda.Stream(device=dev)     # (an explicit stream: NULL means "the context's own")
         c0.set_stream(s1.cuda_stream)
         lat1, dev1 = [], []
-        for it in range(25):
+        for it in range(60):                                # (median of >= 50 iterations after 5 warm-ups)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             fr, dv = frames[it % K], dev_frames[it % K]
