@@ -29,6 +29,19 @@ HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md)
 HBM_COPY_GBS = 6290.0          # measured float4-copy ceiling, same guide (SURVEY.md §8d asks for both)
 
 
+def kernel_source_hash():
+    """sha256 over the library's sources (csrc/ + include/cloudmerge.h): the PMC traffic files under profiles/ carry the hash of
+    the build they were measured on, and a file from another build is not quoted as this one's traffic."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "cloud_merger_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".cpp", ".h", ".hpp")):
+            h.update(name.encode()); h.update(open(os.path.join(csrc, name), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "cloudmerge.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -37,6 +50,7 @@ def parse():
     ap.add_argument("--stream-frames", type=int, default=6, help="distinct frames of the moving stream (6 x 64 MB of input > 256 MiB)")
     ap.add_argument("--jump-every", type=int, default=64, help="every this many frames one reaches 30 %% further out (0: never)")
     ap.add_argument("--static", action="store_true", help="the round-1 loop: one frame resubmitted every step")
+    ap.add_argument("--source-hash", action="store_true", help="print the hash of the kernel sources and exit (scripts/pmc_traffic.sh)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffer (PCIe-inclusive) runs")
     ap.add_argument("--dense", action="store_true", help="config 3: points drawn inside the ROI (the sort-stress variant)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
@@ -185,6 +199,9 @@ def main_fused(args):
 
 
 def main():
+    if "--source-hash" in sys.argv:
+        print(kernel_source_hash())
+        return
     args = parse()
     if args.config == 5:
         return main_fused(args)
@@ -344,7 +361,11 @@ def main():
                                         "note": "enqueue -> result count back on the host, with the other frames in flight"},
                    "frame_interval_ms": {"p50": 1e3 * float(gaps[len(gaps) // 2]), "p99": 1e3 * float(gaps[min(len(gaps) - 1, int(0.99 * len(gaps)))])},
                    "radix_ranking": "lds-add (device probe passed)" if res.path_flags & 1 else "ballot-match",
-                   "path": ("bucket path (cm_kernels_v2.hip + cm_kernels_v3.hip): %d global passes over point records, LDS-local finish%s; box %s"
+                   "path": ("quantile passes (cm_kernels_v4.hip + cm_kernels_v3.hip): ONE global pass over point records into buckets cut "
+                            "at the previous frame's quantiles, one LDS-local finish workgroup per bucket (k3_local + k3_compact); "
+                            "box %s" % ("predicted from the previous frame's bounds" if res.path_flags & 4 else "= crop box"))
+                           if res.path_flags & capi.PATH_QUANTILE else
+                           ("bucket path (cm_kernels_v2.hip + cm_kernels_v3.hip): %d global passes over point records, LDS-local finish%s; box %s"
                             % (res.sort_passes, " (k3_local + k3_compact)" if res.path_flags & capi.PATH_SPLIT else " (k2_local)",
                                "predicted from the previous frame's bounds" if res.path_flags & 4 else "= crop box"))
                            if res.path_flags & 2 else
@@ -385,12 +406,16 @@ def main():
         for k, s in enumerate(sensors):
             cmp.set_transform(k, s.q_xyzw, s.t_xyz)
         acc, order, dev_ms = {}, [], []
-        for it in range(args.profile_frames + 5):
-            for k, s in enumerate(sensors):
-                cmp.submit_device(k, dev_frames[0][k].data_ptr(), s.n, s.point_step, s.off_x, s.off_y, s.off_z, s.off_i)
+        nprof = args.profile_frames + 5
+        for it in range(nprof):
+            # (the stream's frames in turn, ending on frame 0 — the one the parity gate below compares with the oracle)
+            fi = (it - (nprof - 1)) % K
+            for k, s in enumerate(frames[fi]):
+                cmp.set_transform(k, s.q_xyzw, s.t_xyz)
+                cmp.submit_device(k, dev_frames[fi][k].data_ptr(), s.n, s.point_step, s.off_x, s.off_y, s.off_z, s.off_i)
             cmp.merge_voxelize_async(cparams)
             r = cmp.wait()
-            if it < 5:
+            if it < 5 or (r.path_flags & capi.PATH_REDONE):
                 continue
             dev_ms.append(r.device_ms)
             for name, ms in cmp.stage_times():
@@ -399,7 +424,7 @@ def main():
                     order.append(name)
                 acc[name][0] += ms
                 acc[name][1] += 1
-        nf = args.profile_frames
+        nf = max(1, len(dev_ms))
         t_device_ms = float(np.median(dev_ms))
         n_out0 = int(r.n_out)
         b_alg = 16.0 * n_in + 16.0 * n_out0             # read each point once, write each voxel once
@@ -417,13 +442,20 @@ def main():
         traffic, traffic_src = None, None
         suffix = "_bucket" if res.path_flags & 2 else ""
         dense = "_dense" if (args.config == 3 and args.dense) else ""
-        for rnd in ("r2", "r1"):
+        # A file is only quoted for the build it was measured on (its "source_hash" = kernel_source_hash() of that build).
+        src_hash = kernel_source_hash()
+        for rnd in ("r3", "r2", "r1"):
             tpath = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_cfg{args.config}{dense}_minpts{args.min_pts}{suffix}.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
+                if tj.get("source_hash") != src_hash:
+                    traffic_src = {"stale_file": os.path.relpath(tpath, ROOT), "file_source_hash": tj.get("source_hash"),
+                                   "this_build": src_hash, "stale_traffic_high": tj["traffic_high"],
+                                   "note": "measured on another build of the kernels: not quoted (regenerate with scripts/pmc_traffic.sh)"}
+                    break
                 traffic = tj["traffic_high"]
                 traffic_src = {"file": os.path.relpath(tpath, ROOT), "fetch_raw": tj["fetch_raw"], "write": tj["write"],
-                               "fetch_corrected_x2": tj["fetch_x2"], "frames_averaged": tj["frames"]}
+                               "fetch_corrected_x2": tj["fetch_x2"], "frames_averaged": tj["frames"], "source_hash": src_hash}
                 break
         # The path is a sequence of 6 (bucket path) to 11 dependent launches per frame, so the roofline is quoted for
         # the frame: algorithmic bytes (16*N_in + 16*M) over the time a frame takes in
@@ -444,10 +476,11 @@ def main():
                 "t_device_ms": t_alone_ms, "t_device_ms_with_per_kernel_events": t_device_ms,
                 "achieved": alone, "frac": alone / HBM_PEAK_GBS,
                 "dominant_kernel": dom["name"],
-                # the contract's literal per-kernel figure: the frame's algorithmic bytes over the dominant kernel's
-                # average launch duration alone (the headline `achieved` above charges the whole frame instead)
-                "dominant_kernel_achieved": b_alg / (dom["avg_us"] * 1e-6) / 1e9,
-                "dominant_kernel_frac": b_alg / (dom["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                # the contract's literal per-kernel figure: the frame's algorithmic bytes over the time the dominant kernel
+                # takes per frame (all its launches of a frame: us_per_frame below; the headline `achieved` above charges
+                # the whole frame instead)
+                "dominant_kernel_achieved": b_alg / (dom["us_per_frame"] * 1e-6) / 1e9,
+                "dominant_kernel_frac": b_alg / (dom["us_per_frame"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                 "kernels": kernels},
         }
         out_gpu = cmp.result(r.n_out)

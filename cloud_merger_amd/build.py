@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcloudmerge_hip.so")
-SOURCES = ["cm_kernels.hip", "cm_kernels_v2.hip", "cm_kernels_v3.hip", "cm_kernels_ground.hip", "cm_api.cpp"]
+SOURCES = ["cm_kernels.hip", "cm_kernels_v2.hip", "cm_kernels_v3.hip", "cm_kernels_v4.hip", "cm_kernels_ground.hip", "cm_api.cpp"]
 HEADERS = ["cm_device.h", "cm_kernels.h", "cm_common.hpp", os.path.join("..", "..", "include", "cloudmerge.h")]
 
 # -ffp-contract=off / -fno-fast-math: occupancy must match the reference bit for bit, so no FMA

@@ -22,7 +22,7 @@ OK, EMPTY_INPUT, GRID_OVERFLOW, NOT_READY, SKIPPED = 0, 1, 2, 3, 4
 BAD_ARG, HIP_ERROR, NO_DEVICE, CAPACITY, INTERNAL = -1, -2, -3, -4, -5
 FLAG_PROFILE, FLAG_LATEST_WINS, FLAG_OCCUPANCY = 0x1, 0x2, 0x4
 # cm_result.path_flags (CM_PATH_*)
-PATH_LDS_RANK, PATH_BUCKET, PATH_PREDICTED, PATH_REDONE, PATH_PACKED, PATH_SPLIT = 1, 2, 4, 8, 16, 32
+PATH_LDS_RANK, PATH_BUCKET, PATH_PREDICTED, PATH_REDONE, PATH_PACKED, PATH_SPLIT, PATH_QUANTILE = 1, 2, 4, 8, 16, 32, 64
 
 # Every symbol include/cloudmerge.h declares (tests/test_capi_symbols.py checks both directions).
 SYMBOLS = [

@@ -162,6 +162,21 @@ struct cm_ctx {
     int cell_min_b[3] = {0, 0, 0}, cell_div_b[3] = {1, 1, 1};   // grid the cells in out_key are relative to
     uint64_t n_redone = 0;               // frames the bucket path handed back to the classic one
 
+    // quantile passes (cm_kernels_v4.hip): one global pass into buckets cut at the last frame's quantiles
+    int quant_mode = 0;                  // CM_QUANT: 0 auto, 1 never
+    uint32_t* spl[2] = {nullptr, nullptr};   // splitters: a frame reads spl[spl_cur]; its finish writes spl[spl_cur ^ 1]
+    int spl_cur = 0;
+    bool spl_valid = false;              // spl[spl_cur] holds the quantiles of the last finished frame
+    uint32_t spl_n = 0;                  // ... which sorted this many records
+    int32_t spl_min_b[3] = {0, 0, 0}, spl_div_b[3] = {0, 0, 0};   // ... as indices of this grid
+    float spl_inv_leaf[3] = {0, 0, 0};
+    uint32_t *qcnt = nullptr, *qtot = nullptr, *qbofs = nullptr;  // per-tile bucket counts / prefixes, bucket totals, bucket starts
+    bool last_quant = false;             // the frame in flight runs the quantile passes
+    bool wrote_spl = false;              // ... and its finish leaves splitters in spl[spl_cur ^ 1]
+    uint32_t quant_off_frames = 0, quant_backoff = 8;   // after a bucket outgrew the finish: fixed-grid passes for a while
+    int lb_grid_mode = 0, lb_mode = 0;   // the last launch_bucket's arguments (a quantile frame that is handed back is
+    uint32_t lb_g = 0, lb_low = 0;       // redone with the fixed-grid passes in the same box)
+
     // per-sensor figures of the last enqueued frame (cm_frame_stats)
     uint32_t stats_n_sensors = 0;
     uint32_t stats_sensor[CM_MAX_SENSORS] = {0}, stats_n[CM_MAX_SENSORS] = {0}, stats_fresh[CM_MAX_SENSORS] = {0};
@@ -266,6 +281,7 @@ void free_all(cm_ctx* c) {
     F(c->keys_a); F(c->keys_b); F(c->vals_a); F(c->vals_b); F(c->hist); F(c->totals);
     F(c->seg_counts); F(c->seg_tile_counts); F(c->seg_groups); F(c->grp); F(c->partials); F(c->out_key); F(c->out_cnt); F(c->merged_total); F(c->out); F(c->merged); F(c->partial); F(c->table_entries); F(c->mask); F(c->sorted_pts); F(c->rows); F(c->d_state_o);
     F(c->stage32); F(c->out32); F(c->rec_a); F(c->rec_b); F(c->dig); F(c->tile_state); F(c->wave_cnt); F(c->records);
+    F(c->spl[0]); F(c->spl[1]); F(c->qcnt); F(c->qtot); F(c->qbofs);
     F(c->d_ground); F(c->d_state_g); F(c->gmask); F(c->zone_off); F(c->d_planes); F(c->hyp0); F(c->valid0); F(c->counts0); F(c->chunk_sums); F(c->bmask); F(c->zcode);
     F(c->d_frame); F(c->d_tiles); F(c->d_state[0]); F(c->d_state[1]);
     if (c->h_state) (void)hipHostFree(c->h_state);
@@ -505,6 +521,11 @@ int bucket_buffers(cm_ctx* c) {
     if (!c->tile_state) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->tile_state), (npad / 1024 + 2) * 8));
     if (!c->records) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->records), static_cast<size_t>(c->cap_tiles) * 32));
     if (!c->wave_cnt) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->wave_cnt), static_cast<size_t>(c->cap_tiles) * CM2_WAVES * 4));
+    for (auto& p : c->spl)
+        if (!p) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&p), (CM4_BINS + 4) * 4));
+    if (!c->qcnt) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->qcnt), static_cast<size_t>(std::min<uint32_t>(c->cap_tiles, CM4_MAX_TILES)) * (CM4_BINS / 2) * 4));
+    if (!c->qtot) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->qtot), CM4_BINS * 4));
+    if (!c->qbofs) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->qbofs), (CM4_BINS + 4) * 4));
     return CM_OK;
 }
 
@@ -531,10 +552,54 @@ bool pack_survivors(const cm_ctx* c) {
 }
 
 int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits, const unsigned char* mask,
-                  const CmFrameState* st_outlier, int mode = 0) {
+                  const CmFrameState* st_outlier, int mode = 0, bool quant = false) {
     CmFrameDev& f = c->frame;
     hipStream_t st = c->stream;
     { const int e = bucket_buffers(c); if (e != CM_OK) return e; }
+    c->lb_grid_mode = grid_mode; c->lb_g = n_global; c->lb_low = low_bits; c->lb_mode = mode;
+    c->last_quant = quant;
+    c->wrote_spl = false;
+    if (quant) {
+        // One global pass into the buckets the last frame's quantiles cut (cm_kernels_v4.hip), one finish workgroup per bucket.
+        const bool do_setup_q = !c->frame_uploaded_valid || std::memcmp(&f, &c->frame_uploaded, sizeof f) != 0;
+        if (do_setup_q) { c->frame_uploaded = f; c->frame_uploaded_valid = true; }
+        CmFrameState* state = c->d_state[c->cur];
+        CmFrameState* state_next = c->d_state[c->cur ^ 1];
+        const bool predicted = grid_mode == 2;
+        c->from_crop = grid_mode == 1;
+        c->last_v2 = true; c->last_predicted = predicted; c->last_packed = false; c->last_k3 = true;
+        c->frame_mask = nullptr;
+        const uint32_t nt = f.n_tiles;
+        const uint32_t nb = cm_quant_buckets(c->spl_n);
+        const uint32_t* spl = c->spl[c->spl_cur];
+        uint32_t* spl_next = c->spl[c->spl_cur ^ 1];
+        prof_mark(c, "k4_hist");
+        cmk4_hist(st, f, c->d_frame, c->d_tiles, do_setup_q, state, spl, c->qcnt, c->tile_state, f.n_padded / 1024 + 2, c->records,
+                  grid_mode, predicted ? 1 : 0, nt);
+        prof_mark(c, "k4_colscan");
+        cmk4_colscan(st, state, c->h_state_dev, c->qcnt, c->qtot, nt, CM4_CAP);
+        prof_mark(c, "k4_scatter");
+        cmk4_scatter(st, c->d_frame, c->d_tiles, state, spl, c->qcnt, c->qtot, c->qbofs, nb, c->rec_a, c->records, nt,
+                     predicted ? 1 : 0, c->d_tile_kept, nt);
+        // (tile_info: one word pair per bucket; the group totals of the kept voxels behind them — nb + nb / 128 + 1 <= n_padded / 1024 + 2)
+        uint32_t* grp_cnt = reinterpret_cast<uint32_t*>(c->tile_state + nb);
+        uint32_t* skey = c->out_key ? c->keys_a : nullptr;
+        prof_mark(c, "k3_local");
+        cmk3_local(st, c->d_frame, state, c->h_state_dev, c->rec_a, c->tile_state, grp_cnt, c->rec_b, skey, c->vals_a, false, 0u,
+                   0u, spl, c->qbofs, nb, spl_next);
+        c->wrote_spl = true;
+        prof_mark(c, "k3_compact");
+        cmk3_compact(st, state, state_next, c->h_state_dev, c->tile_state, grp_cnt, c->rec_b, skey, c->vals_a, c->out, c->out_key,
+                     c->out_cnt, false, 0u, nb);
+        prof_mark(c, "end");
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(c->ev_done, st));
+        c->cur ^= 1;
+        c->in_flight.store(true);
+        c->pending = true;
+        c->pending_trivial = false;
+        return CM_OK;
+    }
     // (a descriptor that changed since the last frame — new clouds, new poses — goes to HBM with k2_hist0 itself)
     const bool do_setup = !c->frame_uploaded_valid || std::memcmp(&f, &c->frame_uploaded, sizeof f) != 0;
     if (do_setup) {
@@ -604,8 +669,12 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
         uint32_t* grp_cnt = reinterpret_cast<uint32_t*>(c->tile_state + f.n_padded / 2048);
         uint32_t* skey = c->out_key ? c->keys_a : nullptr;
         prof_mark(c, "k3_local");
+        // (the finish also leaves the quantiles of its sorted records: the next frame's splitters, cm_kernels_v4.hip — not
+        // with L = 0, where a tile's sorted range may reach beyond what it holds in LDS)
+        uint32_t* spl_next = (mode == 0 && low_bits != 0) ? c->spl[c->spl_cur ^ 1] : nullptr;
+        c->wrote_spl = spl_next != nullptr;
         cmk3_local(st, c->d_frame, state, c->h_state_dev, rec_sorted, c->tile_state, grp_cnt, stage, skey, c->vals_a, mode == 1,
-                   low_bits, nt_later * CM_TILE);
+                   low_bits, nt_later * CM_TILE, nullptr, nullptr, 0u, spl_next);
         prof_mark(c, "k3_compact");
         cmk3_compact(st, state, state_next, c->h_state_dev, c->tile_state, grp_cnt, stage, skey, c->vals_a,
                      mode == 1 ? c->partial : c->out, c->out_key, c->out_cnt, mode == 1, nt_later * CM_TILE);
@@ -702,6 +771,10 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
     c->last_key_bits = key_bits;
     c->last_v2 = false;
     c->last_predicted = false;
+    const bool spl_ok = c->spl_valid;        // (valid again once this frame has finished and left its own splitters)
+    c->spl_valid = false;
+    c->wrote_spl = false;
+    c->last_quant = false;
 
     // Bucket path: centroids of one GPU's whole frame, with a box known before the first point is
     // read — the crop box, or the last frame's bounds plus a margin (verified on the device).
@@ -743,7 +816,19 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
             const uint32_t g = bucket_passes(kb, est, c->v2_extra_passes);
             if (g) {
                 const uint32_t low = kb > 8 * g ? kb - 8 * g : 0;
-                if (!pre) return launch_bucket(c, gm, g, low, nullptr, nullptr, mode);
+                // Quantile passes (one global pass instead of g): the last frame of this context left the quantiles of its
+                // sorted records, as indices of this very grid, and this frame is about as large.
+                bool quant = mode == 0 && !pre && c->quant_mode != 1 && c->finish_mode != 2 && spl_ok && g >= 2 && low != 0 &&
+                             kb < 32 && f.n_tiles <= CM4_MAX_TILES && !(gm == 1 && pack_survivors(c)) &&
+                             std::memcmp(c->spl_min_b, f.box_min_b, sizeof c->spl_min_b) == 0 &&
+                             std::memcmp(c->spl_div_b, f.box_div_b, sizeof c->spl_div_b) == 0 &&
+                             std::memcmp(c->spl_inv_leaf, f.inv_leaf, sizeof c->spl_inv_leaf) == 0;
+                if (quant) {
+                    const uint32_t nb = cm_quant_buckets(c->spl_n);
+                    quant = nb != 0 && c->spl_n / nb <= CM4_MAX_AVG && est <= 2ull * c->spl_n + CM_TILE;
+                }
+                if (quant && c->quant_off_frames) { --c->quant_off_frames; quant = false; }
+                if (!pre) return launch_bucket(c, gm, g, low, nullptr, nullptr, mode, quant);
                 c->post_bucket = true; c->post_g = g; c->post_low = low;
                 // the outlier stage's own sort can use the bucket kernels as well: the crop box fixes its grid too
                 c->pre_bucket = gm_o == 1 && box_grid(p->crop_min, p->crop_max, inv_cell, &kb_o, f.cell_min_b, f.cell_div_b) &&
@@ -997,6 +1082,24 @@ int wait_frame(cm_ctx* c, cm_result* res) {
             // bucket did not fit LDS, or when a workgroup gave up waiting for its predecessors: the
             // classic path redoes it (the sensors' clouds are still in place) and the cause is dealt with.
             const CmFrameState& h0 = *c->h_state;
+            // A frame of the quantile passes whose buckets did not come out as predicted (one too large for the finish, or —
+            // never seen — an index outside its bucket's range): the splitters are stale. Redone at once with the fixed-grid
+            // passes in the same box, which leave fresh splitters; the quantile passes rest for a few frames.
+            const bool quant_fail = c->last_quant && !h0.outside &&
+                                    (h0.err == CM_DEV_ERR_QUANT || h0.err == CM_DEV_ERR_UNSORTED || h0.err == CM_DEV_ERR_BUCKET);
+            if (quant_fail) {
+                c->quant_off_frames = c->quant_backoff;
+                if (c->quant_backoff < 1024) c->quant_backoff *= 2;
+                ++c->n_redone;
+                redone = true;
+                c->h_state->err = 0;
+                c->prof_used = 0;
+                const int e = launch_bucket(c, c->lb_grid_mode, c->lb_g, c->lb_low, nullptr, nullptr, c->lb_mode, false);
+                if (e != CM_OK) { c->pending = false; return e; }
+                HIP_TRY(c, hipEventSynchronize(c->ev_done));
+                c->in_flight.store(false);
+            }
+            // (h0 is the host record: by now the redone frame's, should there have been one)
             if (h0.outside || h0.err == CM_DEV_ERR_BUCKET || h0.err == CM_DEV_ERR_BUCKET_PRE || h0.err == CM_DEV_ERR_LOOKBACK ||
                 h0.err == CM_DEV_ERR_UNSORTED || h0.err == CM_DEV_ERR_GRID) {
                 if (h0.err == CM_DEV_ERR_GRID) c->grid_shrink_off = 64;   // more records than the last frame promised: whole grids for a while
@@ -1014,7 +1117,7 @@ int wait_frame(cm_ctx* c, cm_result* res) {
                     if (c->pre_bucket_backoff < (1u << 20)) c->pre_bucket_backoff *= 2;
                 }
                 if (h0.err == CM_DEV_ERR_LOOKBACK) c->v2_off_frames = 0xFFFFFFFFu;
-                ++c->n_redone;
+                if (!redone) ++c->n_redone;
                 redone = true;
                 bool settled = false;
                 if (redo_in_measured_box(c, h0)) {            // (a box miss and nothing else: the same path, in a box that fits)
@@ -1079,7 +1182,8 @@ int wait_frame(cm_ctx* c, cm_result* res) {
         r.key_bits = h.key_bits;
         r.sort_passes = h.n_passes;
         r.path_flags = (c->lds_rank ? 1u : 0u) | (c->last_v2 ? 2u : 0u) | (c->last_predicted ? 4u : 0u) | (redone ? 8u : 0u) |
-                       ((c->last_v2 && c->last_packed) ? 16u : 0u) | ((c->last_v2 && c->last_k3) ? 32u : 0u);
+                       ((c->last_v2 && c->last_packed) ? 16u : 0u) | ((c->last_v2 && c->last_k3) ? 32u : 0u) |
+                       ((c->last_v2 && c->last_quant) ? 64u : 0u);
         if (c->last_predicted && h.status == CM_OK) {
             // The device sorted by cells of the predicted box (same order); the grid PCL itself would
             // report comes from the cloud's exact bounds, which the frame also produced (A.4 steps 2, 4).
@@ -1102,6 +1206,16 @@ int wait_frame(cm_ctx* c, cm_result* res) {
             update_predicted_box(c, h.min_p, h.max_p, leaf);
         }
         if (h.status == CM_OK) c->last_n_merged = h.n_valid;
+        if (h.status == CM_OK && c->last_v2 && c->wrote_spl && h.n_valid) {
+            // the finish left the quantiles of this frame's sorted records: the next frame's splitters (cm_kernels_v4.hip)
+            c->spl_cur ^= 1;
+            c->spl_valid = true;
+            c->spl_n = h.n_valid;
+            std::memcpy(c->spl_min_b, c->frame.box_min_b, sizeof c->spl_min_b);
+            std::memcpy(c->spl_div_b, c->frame.box_div_b, sizeof c->spl_div_b);
+            std::memcpy(c->spl_inv_leaf, c->frame.inv_leaf, sizeof c->spl_inv_leaf);
+            if (c->last_quant && !redone && c->quant_backoff > 8) --c->quant_backoff;
+        }
         if (h.status == CM_OK) {
             r.n_merged = h.n_valid;
             r.n_out = h.n_out;
@@ -1227,6 +1341,7 @@ int cm_create(cm_ctx** out, int device, const cm_limits* lim) {
     }
     if (const char* fm = getenv("CM_FINISH")) c->finish_mode = std::strcmp(fm, "v2") == 0 ? 2 : 0;
     if (const char* dm = getenv("CM_DEBUG_MISRANK")) c->debug_misrank = dm[0] == '1' ? 1 : 0;
+    if (const char* qm = getenv("CM_QUANT")) c->quant_mode = qm[0] == '0' ? 1 : 0;     // CM_QUANT=0: fixed-grid passes only
     if (!ok) {
         free_all(c);
         delete c;

@@ -33,6 +33,23 @@
 // (the local finish's geometry — 2048-record tiles, room for 4032 (k3_local) / 4096 (k2_local), 512 threads — is fixed where it is launched)
 #define CM2_MAX_LOW_BITS 14   // key bits left to the local finish when the global passes allow it
 
+// Quantile passes (cm_kernels_v4.hip): ONE global pass into up to CM4_BINS buckets cut at the quantiles of the previous
+// frame's sorted records (about CM4_TARGET records each), one finish workgroup per bucket (room for CM4_CAP records).
+#define CM4_BINS 2048
+#define CM4_TARGET 1920u
+#define CM4_CAP 4032u
+#define CM4_MAX_AVG 2600u     // the host takes the path only while records / buckets stays below this
+#define CM4_MAX_TILES 1536u   // ... and the frame has at most this many 4096-slot tiles (k4_colscan's register tile)
+// Buckets the NEXT frame uses when this one sorted n records (the finish writes that many splitters; the host sizes the grids).
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline uint32_t cm_quant_buckets(uint32_t n) {
+    if (n == 0) return 0;
+    const uint32_t b = (n + CM4_TARGET - 1u) / CM4_TARGET;
+    return b > CM4_BINS ? CM4_BINS : b;
+}
+
 // Point layouts the loaders special-case.
 #define CM_LAYOUT_XYZI16 0    // x,y,z,intensity @0,4,8,12, step 16, 16-B aligned: one dwordx4 load
 #define CM_LAYOUT_PCL32 1     // pcl::PointXYZI image, step 32, intensity @16: dwordx4 + dword
@@ -116,7 +133,8 @@ struct CmGroundPlaneDev {                 // == cm_ground_plane
 // Per-frame device state, zeroed before the first kernel of a frame.
 struct CmFrameState {
     uint32_t outside;         // bucket path: a point fell outside the predicted box (frame must be redone)
-    uint32_t _unused[5];
+    uint32_t quant_abort;     // quantile passes (cm_kernels_v4.hip): a bucket beyond the finish's capacity — every later kernel leaves
+    uint32_t _unused[4];
     uint32_t n_valid_k0;      // valid points counted by the min/max pass
     int32_t status;           // cm_status of the frame (0 OK, 1 EMPTY, 2 OVERFLOW)
     int32_t min_b[3], max_b[3], div_b[3];
@@ -138,6 +156,7 @@ struct CmFrameState {
 #define CM_DEV_ERR_BUCKET 4u     // ... a bucket did not fit the local finish's LDS capacity
 #define CM_DEV_ERR_BUCKET_PRE 5u // ... the same in the outlier stage's sort (a radius cell with thousands of points)
 #define CM_DEV_ERR_GRID 6u       // ... the kernels behind pass 0 were launched with fewer workgroups than the kept records need
+#define CM_DEV_ERR_QUANT 7u      // ... a quantile bucket (cm_kernels_v4.hip) grew beyond the finish's capacity: the splitters are stale
 #define CM_DEV_OUTLIER_GRID 3   // the radius grid of the outlier stage does not fit (rows or 32-bit index)
 #define CM_DEV_ABORTED 4        // a stage gave up (CmFrameState.err says why): every later kernel of the frame leaves at once —
                                 // what the stage left behind (half-sorted keys, unwritten records) must not be indexed with

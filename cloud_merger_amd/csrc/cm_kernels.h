@@ -68,12 +68,27 @@ void cmk2_local_sort(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint
 
 // ---- voxel finish of the bucket path, second generation (cm_kernels_v3.hip): k3_local + k3_compact
 // tile_info: one uint2 per 2048-record tile; grp_cnt: one zeroed word per 64 tiles; stage: 16 B (32 B: partial) per record slot
+// spl / bofs / n_buckets: the records are grouped by quantile bucket (cm_kernels_v4.hip): one workgroup per bucket;
+// spl_next: where the finish leaves the next frame's splitters (CM4_BINS + 1 words; nullptr: none)
 void cmk3_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* host_state, const void* rec, void* tile_info,
                 uint32_t* grp_cnt, void* stage, uint32_t* stage_key, uint32_t* stage_cnt, bool partial, uint32_t low_bits,
-                uint32_t n_slots);                         // n_slots / 2048 workgroups (n_padded, or what the records are expected to need)
+                uint32_t n_slots,                          // n_slots / 2048 workgroups (n_padded, or what the records are expected to need)
+                const uint32_t* spl = nullptr, const uint32_t* bofs = nullptr, uint32_t n_buckets = 0, uint32_t* spl_next = nullptr);
 void cmk3_compact(hipStream_t s, const CmFrameState* st, CmFrameState* st_next, uint32_t* host_state, const void* tile_info,
                   const uint32_t* grp_cnt, const void* stage, const uint32_t* stage_key, const uint32_t* stage_cnt, void* out,
-                  uint32_t* out_key, uint32_t* out_cnt, bool partial, uint32_t n_padded);
+                  uint32_t* out_key, uint32_t* out_cnt, bool partial, uint32_t n_padded, uint32_t n_buckets = 0);
+
+// ---- quantile passes (cm_kernels_v4.hip): one global pass into balanced buckets, then k3_local per bucket
+// spl: CM4_BINS + 1 splitters (ascending indices, spl[0] = 0, 0xFFFFFFFF beyond the frame's buckets); cnt: n_tiles rows of
+// CM4_BINS 16-bit counters; totals: CM4_BINS words; bofs: CM4_BINS + 1 words (first record of every bucket, total)
+void cmk4_hist(hipStream_t s, const CmFrameDev& f, CmFrameDev* fd, CmTileDev* tiles, bool do_setup, CmFrameState* st,
+               const uint32_t* spl, uint32_t* cnt, unsigned long long* tile_state, uint32_t n_tile_state, float* records,
+               int grid_mode, int check_box, uint32_t n_tiles);
+void cmk4_colscan(hipStream_t s, CmFrameState* st, uint32_t* host_state, uint32_t* cnt, uint32_t* totals, uint32_t n_tiles,
+                  uint32_t cap);
+void cmk4_scatter(hipStream_t s, const CmFrameDev* fd, const CmTileDev* tiles, CmFrameState* st, const uint32_t* spl,
+                  const uint32_t* cnt, const uint32_t* totals, uint32_t* bofs, uint32_t n_buckets, void* rec_out,
+                  const float* records, uint32_t n_records, int fold, uint32_t* tile_kept, uint32_t n_tiles);
 
 // ---- zone-wise ground removal (cm_kernels_ground.hip) ------------------------------------------
 void cmkg_setup(hipStream_t s, const CmGroundDev& g, CmGroundDev* d_ground);

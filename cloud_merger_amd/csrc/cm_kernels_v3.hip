@@ -90,7 +90,7 @@ __device__ unsigned long long g_phase3[4096 * 16];
 // ------------------------------------------------------------------------------------------------
 // k3_local
 // ------------------------------------------------------------------------------------------------
-template <int LT, int LCAP, int LBLOCK, int WPS, bool PARTIAL>
+template <int LT, int LCAP, int LBLOCK, int WPS, bool PARTIAL, bool QUANT>
 __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __restrict__ fd,
                                                       CmFrameState* __restrict__ st,
                                                       uint32_t* __restrict__ host_state,
@@ -100,7 +100,12 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
                                                       float4* __restrict__ stage,
                                                       uint32_t* __restrict__ stage_key,
                                                       uint32_t* __restrict__ stage_cnt,
-                                                      uint32_t low_bits) {
+                                                      uint32_t low_bits,
+                                                      const uint32_t* __restrict__ spl, const uint32_t* __restrict__ bofs,
+                                                      uint32_t n_buckets, uint32_t* __restrict__ spl_next) {
+    // QUANT (cm_kernels_v4.hip): the records are grouped by quantile bucket — workgroup t takes bucket t, records
+    // [bofs[t], bofs[t+1]) with indices in [spl[t], spl[t+1]): no bucket boundaries to look for, no tail to follow.
+    // spl_next: where the next frame's splitters go (every tile writes the quantiles that fall into its sorted range).
     constexpr int LWAVES = LBLOCK / 64, LITEMS = (LCAP + LBLOCK - 1) / LBLOCK, EXT0 = LBLOCK < 256 ? LBLOCK : 256;
     constexpr int BINS = 1024, HWORDS = BINS / 2;          // two 16-bit counters per LDS word
     static_assert(LT == 4 * LBLOCK && LCAP <= 0x7FFE && HWORDS <= LBLOCK && LWAVES * HWORDS * 2 >= LCAP, "tile geometry");
@@ -117,18 +122,41 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
     const int lane = threadIdx.x & 63;
     const uint32_t w = SCAL(threadIdx.x >> 6);
     if (st->status != CM_DEV_OK || st->outside) return;          // (k3_compact reports)
+    if (QUANT && st->quant_abort) return;
     const uint32_t n = SCAL(st->n_valid);
-    const uint32_t n_lt = (n + LT - 1) / LT;
+    const uint32_t n_lt = QUANT ? n_buckets : (n + LT - 1) / LT;
     const uint32_t tile = blockIdx.x;
     if (tile >= n_lt) return;
     const BoxGrid b = box_grid_of(fd);
-    const uint32_t L = low_bits;
+    const uint32_t L = QUANT ? 1u : low_bits;                    // (QUANT: only "there is something left to sort")
     const uint32_t min_pts = SCAL((!PARTIAL && fd->min_pts > 1) ? fd->min_pts : 1u);
 
     // ---- load: the nominal tile, the key before it, and the first records after it
-    const uint32_t base = tile * LT;
-    const uint32_t nom = min(static_cast<uint32_t>(LT), n - base);
-    {
+    const uint32_t base = QUANT ? SCAL(bofs[tile]) : tile * LT;
+    const uint32_t q_end = QUANT ? SCAL(bofs[tile + 1]) : 0u;
+    const bool q_big = QUANT && (q_end - base) > static_cast<uint32_t>(LCAP);
+    const uint32_t nom = QUANT ? (q_big ? 0u : q_end - base) : min(static_cast<uint32_t>(LT), n - base);
+    const uint32_t q_lo = QUANT ? SCAL(spl[tile]) : 0u;
+    const uint32_t q_hi = QUANT ? min(SCAL(spl[tile + 1]), fd->box_key_bits < 32u ? (1u << fd->box_key_bits) : 0xFFFFFFFFu) : 0u;
+    bool q_bad = false;
+    if (QUANT) {
+        float4 r4[LITEMS];
+#pragma unroll
+        for (int r = 0; r < LITEMS; ++r) {
+            const uint32_t q = r * LBLOCK + threadIdx.x;
+            r4[r] = (q < nom) ? rec[base + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int r = 0; r < LITEMS; ++r) {
+            const uint32_t q = r * LBLOCK + threadIdx.x;
+            if (q < nom) {
+                const uint32_t k = key_of(b, r4[r]);
+                sk[q] = k;
+                q_bad = q_bad || k < q_lo || k >= q_hi;          // (the scatter put a record into a bucket that is not its own)
+            }
+        }
+        if (threadIdx.x == 0) { s_keyprev = 0u; s_a = 0u; s_bad = 0u; s_njobs = 0u; }
+    } else {
         float4 r4[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -152,8 +180,8 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
     PH3(0);
 
     // ---- a: first bucket start in the nominal tile; H must not decrease anywhere (free check of the global passes)
-    bool bad_order = false;
-    {
+    bool bad_order = q_bad;
+    if (!QUANT) {
         uint32_t best = 0xFFFFFFFFu;
 #pragma unroll
         for (int r = 3; r >= 0; --r) {
@@ -167,18 +195,18 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
         }
         if (best != 0xFFFFFFFFu) atomicMin(&s_a, best);
     }
-    const uint32_t h_last = SCAL(sk[nom - 1] >> L);
+    const uint32_t h_last = QUANT ? 0u : SCAL(sk[nom - 1] >> L);
     // ---- tail of the last bucket past the nominal end (a prefix of what follows: H is ascending)
-    const bool in_e = threadIdx.x < EXT0 && nom == LT && (base + LT + threadIdx.x) < n;
+    const bool in_e = !QUANT && threadIdx.x < EXT0 && nom == LT && (base + LT + threadIdx.x) < n;
     const bool m0 = in_e && (sk[LT + threadIdx.x] >> L) == h_last;
     bad_order = bad_order || (in_e && (sk[LT + threadIdx.x] >> L) < h_last);
-    uint32_t ext = SCAL(__syncthreads_count(m0));         // also orders the atomicMin above
+    uint32_t ext = QUANT ? 0u : SCAL(__syncthreads_count(m0));         // also orders the atomicMin above
     const uint32_t a = SCAL(s_a);
     // With no bits left to sort (L == 0: a bucket is ONE voxel, its records already in their final order) a voxel need not
     // fit: what LDS cannot hold is read straight from HBM when its sum is finished ("open tail", the long-run jobs below).
     const bool may_open = L == 0 && (min_pts - 1u) < static_cast<uint32_t>(LCAP - LT);
-    bool too_big = false, tail_open = false;
-    if (ext == EXT0 && a != 0xFFFFFFFFu) {
+    bool too_big = q_big, tail_open = false;
+    if (!QUANT && ext == EXT0 && a != 0xFFFFFFFFu) {
         for (uint32_t off = EXT0;; off += LBLOCK) {
             const uint32_t j = base + LT + off + threadIdx.x;
             const uint32_t pos = LT + off + threadIdx.x;
@@ -211,9 +239,10 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
         __syncthreads();
     }
     if (m && L != 0) {
-        const uint32_t h_first = SCAL(sk[a] >> L);
-        const uint32_t kbase = h_first << L;
-        const unsigned long long span = static_cast<unsigned long long>(h_last - h_first + 1u) << L;
+        const uint32_t h_first = QUANT ? 0u : SCAL(sk[a] >> L);
+        const uint32_t kbase = QUANT ? q_lo : h_first << L;
+        const unsigned long long span = QUANT ? static_cast<unsigned long long>(q_hi - q_lo)
+                                              : static_cast<unsigned long long>(h_last - h_first + 1u) << L;
         const uint32_t nb = span > 1ull ? 64u - static_cast<uint32_t>(__builtin_clzll(span - 1ull)) : 0u;
         const uint32_t npass = nb ? (nb + 9u) / 10u : 1u;
         const uint32_t width = nb ? (nb + npass - 1u) / npass : 0u;
@@ -291,6 +320,24 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
     }
     if (s_bad && threadIdx.x == 0) host_state[offsetof(CmFrameState, err) / 4] = CM_DEV_ERR_UNSORTED;
     PH3(2);
+
+    // ---- the next frame's splitters (cm_kernels_v4.hip): sorted position e of this tile is record base + a + e of the whole
+    // frame in index order; quantile j of bn sits at record floor(j * n / bn). Each is written by the one tile whose range
+    // holds it; tile 0 also writes the fixed ends (splitter 0 = index 0, 0xFFFFFFFF beyond the last bucket).
+    if (!PARTIAL && spl_next) {
+        const uint32_t bn = cm_quant_buckets(n);
+        if (bn && m) {
+            const unsigned long long g0 = static_cast<unsigned long long>(base) + a, g1 = g0 + m;
+            const uint32_t j_lo = static_cast<uint32_t>((g0 * bn + n - 1ull) / n);
+            for (uint32_t j = j_lo + threadIdx.x; j < bn; j += LBLOCK) {
+                const unsigned long long pj = static_cast<unsigned long long>(j) * n / bn;
+                if (pj >= g1) break;
+                spl_next[j] = j ? sk[si[static_cast<uint32_t>(pj - g0)]] : 0u;
+            }
+        }
+        if (tile == 0)
+            for (uint32_t j = bn + threadIdx.x; j <= CM4_BINS; j += LBLOCK) spl_next[j] = 0xFFFFFFFFu;
+    }
 
     // ---- voxels. Thread t takes the sorted positions [t*per, (t+1)*per). A head is a position whose key differs from
     // the one before it; its voxel is kept when the position min_pts - 1 further on still has its key (A.4 step 7).
@@ -537,7 +584,7 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
     }
     PH3(5);
     if (threadIdx.x == 0) {
-        tile_info[tile] = make_uint2(a == 0xFFFFFFFFu ? 0u : a, c_t);
+        tile_info[tile] = make_uint2(QUANT ? base : (a == 0xFFFFFFFFu ? 0u : a), c_t);   // (QUANT: a == 0; where the tile's centroids start)
         if (c_t) atomicAdd(&grp_cnt[tile >> 6], c_t);
     }
 }
@@ -552,7 +599,8 @@ __global__ __launch_bounds__(256) void k3_compact(const CmFrameState* __restrict
                                                   const uint32_t* __restrict__ grp_cnt, const float4* __restrict__ stage,
                                                   const uint32_t* __restrict__ stage_key, const uint32_t* __restrict__ stage_cnt,
                                                   float4* __restrict__ out, uint32_t* __restrict__ out_key,
-                                                  uint32_t* __restrict__ out_cnt) {
+                                                  uint32_t* __restrict__ out_cnt, uint32_t n_buckets) {
+    // n_buckets != 0: the finish ran one workgroup per quantile bucket (k3_local<QUANT>): tile_info[t].x is the absolute start
     __shared__ uint32_t lds[4];
     if (blockIdx.x == 0 && st_next && threadIdx.x < sizeof(CmFrameState) / 4)
         reinterpret_cast<uint32_t*>(st_next)[threadIdx.x] = 0;
@@ -565,8 +613,12 @@ __global__ __launch_bounds__(256) void k3_compact(const CmFrameState* __restrict
         if (blockIdx.x == 0) report_state(host_state, st, CM_DEV_EMPTY, 0u, true);
         return;
     }
-    const uint32_t n_lt = (n + LT - 1) / LT;
+    const uint32_t n_lt = n_buckets ? n_buckets : (n + LT - 1) / LT;
     const uint32_t tile = blockIdx.x;
+    if (n_buckets && st->quant_abort) {                          // (k4_colscan gave the frame back; its error word is in place)
+        if (blockIdx.x == 0) report_state(host_state, st, st->status, 0u, true);
+        return;
+    }
     // The kernels behind pass 0 may have been launched for fewer records than the frame's slots (a crop box that dropped
     // most points of the last frame: cm_api.cpp launch_bucket): more records than that, and the frame is handed back.
     if (tile == 0 && threadIdx.x == 0 && n_lt > gridDim.x) host_state[offsetof(CmFrameState, err) / 4] = CM_DEV_ERR_GRID;
@@ -582,7 +634,7 @@ __global__ __launch_bounds__(256) void k3_compact(const CmFrameState* __restrict
     __syncthreads();
     const uint32_t prefix = lds[0] + lds[1] + lds[2] + lds[3];
     if (tile == n_lt - 1) report_state(host_state, st, CM_DEV_OK, prefix + info.y, true);
-    const size_t src = static_cast<size_t>(tile) * LT + info.x;
+    const size_t src = n_buckets ? static_cast<size_t>(info.x) : static_cast<size_t>(tile) * LT + info.x;
     for (uint32_t q = threadIdx.x; q < info.y; q += 256) {
         if (PARTIAL) {
             out[2 * (static_cast<size_t>(prefix) + q)] = stage[2 * (src + q)];
@@ -609,31 +661,36 @@ extern "C" __attribute__((visibility("default"))) void cm_debug_phases3(unsigned
 
 void cmk3_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* host_state, const void* rec, void* tile_info,
                 uint32_t* grp_cnt, void* stage, uint32_t* stage_key, uint32_t* stage_cnt, bool partial, uint32_t low_bits,
-                uint32_t n_padded) {
+                uint32_t n_padded, const uint32_t* spl, const uint32_t* bofs, uint32_t n_buckets, uint32_t* spl_next) {
     // 2048-record tiles, room for 4032 (bucket tails of up to 1984 records), 512 threads at no more than 64 registers:
     // 40 912 bytes of LDS — four workgroups per CU, all eight wave slots of every SIMD (44 us at cfg2; with room for 4096 the
-    // fourth workgroup does not fit the CU's 160 KiB: 47 us)
-    const dim3 grid(n_padded / 2048);
-    if (partial)
-        hipLaunchKernelGGL((k3_local<2048, 4032, 512, 8, true>), grid, dim3(512), 0, s, fd, st, host_state,
+    // fourth workgroup does not fit the CU's 160 KiB: 47 us). n_buckets != 0: one workgroup per quantile bucket (cm_kernels_v4.hip).
+    static_assert(CM4_CAP == 4032, "k4_colscan's capacity check is this kernel's LCAP");
+    const dim3 grid(n_buckets ? n_buckets : n_padded / 2048);
+    if (n_buckets)
+        hipLaunchKernelGGL((k3_local<2048, 4032, 512, 8, false, true>), grid, dim3(512), 0, s, fd, st, host_state,
                            reinterpret_cast<const float4*>(rec), reinterpret_cast<uint2*>(tile_info), grp_cnt,
-                           reinterpret_cast<float4*>(stage), nullptr, nullptr, low_bits);
+                           reinterpret_cast<float4*>(stage), stage_key, stage_cnt, low_bits, spl, bofs, n_buckets, spl_next);
+    else if (partial)
+        hipLaunchKernelGGL((k3_local<2048, 4032, 512, 8, true, false>), grid, dim3(512), 0, s, fd, st, host_state,
+                           reinterpret_cast<const float4*>(rec), reinterpret_cast<uint2*>(tile_info), grp_cnt,
+                           reinterpret_cast<float4*>(stage), nullptr, nullptr, low_bits, nullptr, nullptr, 0u, nullptr);
     else
-        hipLaunchKernelGGL((k3_local<2048, 4032, 512, 8, false>), grid, dim3(512), 0, s, fd, st, host_state,
+        hipLaunchKernelGGL((k3_local<2048, 4032, 512, 8, false, false>), grid, dim3(512), 0, s, fd, st, host_state,
                            reinterpret_cast<const float4*>(rec), reinterpret_cast<uint2*>(tile_info), grp_cnt,
-                           reinterpret_cast<float4*>(stage), stage_key, stage_cnt, low_bits);
+                           reinterpret_cast<float4*>(stage), stage_key, stage_cnt, low_bits, nullptr, nullptr, 0u, spl_next);
 }
 
 void cmk3_compact(hipStream_t s, const CmFrameState* st, CmFrameState* st_next, uint32_t* host_state, const void* tile_info,
                   const uint32_t* grp_cnt, const void* stage, const uint32_t* stage_key, const uint32_t* stage_cnt, void* out,
-                  uint32_t* out_key, uint32_t* out_cnt, bool partial, uint32_t n_padded) {
-    const dim3 grid(n_padded / 2048);
+                  uint32_t* out_key, uint32_t* out_cnt, bool partial, uint32_t n_padded, uint32_t n_buckets) {
+    const dim3 grid(n_buckets ? n_buckets : n_padded / 2048);
     if (partial)
         hipLaunchKernelGGL((k3_compact<2048, true>), grid, dim3(256), 0, s, st, st_next, host_state,
                            reinterpret_cast<const uint2*>(tile_info), grp_cnt, reinterpret_cast<const float4*>(stage),
-                           nullptr, nullptr, reinterpret_cast<float4*>(out), nullptr, nullptr);
+                           nullptr, nullptr, reinterpret_cast<float4*>(out), nullptr, nullptr, 0u);
     else
         hipLaunchKernelGGL((k3_compact<2048, false>), grid, dim3(256), 0, s, st, st_next, host_state,
                            reinterpret_cast<const uint2*>(tile_info), grp_cnt, reinterpret_cast<const float4*>(stage),
-                           stage_key, stage_cnt, reinterpret_cast<float4*>(out), out_key, out_cnt);
+                           stage_key, stage_cnt, reinterpret_cast<float4*>(out), out_key, out_cnt, n_buckets);
 }

@@ -111,6 +111,10 @@ typedef struct cm_result {
                                   packed while counting, so the raw clouds were read once instead of twice */
 #define CM_PATH_SPLIT 32u      /* bucket path, finish by k3_local + k3_compact (tiles stage their centroids, a second launch
                                   packs them: no look-back between tiles); otherwise k2_local */
+#define CM_PATH_QUANTILE 64u   /* bucket path, ONE global pass (sort_passes == 1) into buckets cut at the quantiles of the previous
+                                  frame's sorted records (same grid), one finish workgroup per bucket; bucket sizes are verified
+                                  on the device, a frame whose buckets outgrew the finish is redone with the fixed-grid passes
+                                  (CM_PATH_REDONE). The points of a voxel are added in the same (sensor, point) order: same results */
 #define CM_PATH_REDONE 8u      /* the bucket path gave the frame back and it was computed a second time inside cm_wait: after
                                   a point outside the predicted box on the bucket path again, in a box around the bounds the
                                   first attempt measured (CM_PATH_BUCKET | CM_PATH_PREDICTED stay set); after a bucket too large

@@ -19,7 +19,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     per = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
         if r.get("Counter_Name") != c: continue
-        m = re.search(r"(k[23]?_\w+)", r["Kernel_Name"])
+        m = re.search(r"(k[234]?_\w+)", r["Kernel_Name"])
         if not m: continue
         per[m.group(1)][0] += float(r["Counter_Value"]); per[m.group(1)][1] += 1
     res[c] = {k: {"sum_kb": v[0], "dispatches": v[1]} for k, v in per.items()}
@@ -39,6 +39,9 @@ for k in sorted(set(res["FETCH_SIZE"]) | set(res["WRITE_SIZE"])):
 out["fetch_raw"] = tot_f; out["fetch_x2"] = 2 * tot_f; out["write"] = tot_w
 out["traffic_low"] = tot_f + tot_w; out["traffic_high"] = 2 * tot_f + tot_w
 out["algorithmic_bytes_per_frame"] = bench["roofline"]["algorithmic_bytes_per_frame"]
+import subprocess
+out["source_hash"] = subprocess.run([sys.executable, "bench.py", "--source-hash"], capture_output=True, text=True).stdout.strip()
+out["path"] = bench["config"]["path"]
 json.dump(out, open(f"gpurun_out/{tag}_traffic.json", "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("frames", "fetch_raw", "fetch_x2", "write", "traffic_low", "traffic_high", "algorithmic_bytes_per_frame")}))
 for k, v in out["kernels"].items(): print("%-14s fetch_raw %8.1f MB  write %8.1f MB" % (k, v["fetch_raw"] / 1e6, v["write"] / 1e6))

@@ -1,0 +1,135 @@
+"""GPU parity of the quantile passes (cm_kernels_v4.hip): ONE global pass into buckets cut at the quantiles of the
+previous frame's sorted records, then one finish workgroup per bucket — against the CPU oracle, through the C-ABI.
+
+The path needs a predecessor: the first frame of a context (and every frame whose grid changed) runs the fixed-grid
+passes and leaves the splitters; from the second frame on cm_result.path_flags carries CM_PATH_QUANTILE. Same bars as
+tests/test_gpu_parity.py: merged cloud and occupancy bit-exact, centroids bit-exact for voxels of up to 17 points
+(tests/util.py) and within 1e-4 m beyond."""
+import numpy as np
+import pytest
+
+from cloud_merger_amd import capi, synth
+from cloud_merger_amd.types import MergeParams, SensorCloud, xyzi_cloud
+from oracle import oracle
+from tests.util import assert_bucket_centroids, assert_centroids_close_or_exact, same_bits, xyzi_of
+
+pytestmark = pytest.mark.gpu
+
+BUCKET, PREDICTED, REDONE, SPLIT, QUANTILE = 2, 4, 8, 32, 64
+
+
+def xyzi4(a):
+    return np.stack([a["x"], a["y"], a["z"], a["intensity"]], axis=1)
+
+
+def frame_against_oracle(cm, sensors, params, n_cap):
+    """One frame on a persistent context, compared with the oracle like tests/test_gpu_parity.py::check_against_oracle."""
+    st, merged, out, rep = oracle.merge_voxelize(sensors, params, threads=4, stable=True)
+    cm.submit_all(sensors)
+    res = cm.merge_voxelize(params)
+    assert res.status == st
+    assert res.n_in == rep.n_in
+    got_merged = xyzi4(cm.merged(n_cap))
+    assert same_bits(got_merged, xyzi_of(merged)), "merged cloud (transform + crop + concat) must be bit-exact"
+    if st != oracle.OK:
+        return res, rep
+    got = xyzi4(cm.result(res.n_out))
+    cells, counts = cm.cells(res.n_out)
+    assert res.n_merged == rep.n_merged
+    assert res.n_out == rep.n_out, "occupancy: number of kept voxels"
+    assert np.array_equal(cells, rep.cells), "occupancy: kept cells and their order"
+    assert np.array_equal(counts, rep.counts), "occupancy: points per voxel"
+    if res.path_flags & BUCKET:          # (a frame handed back twice ends on the general path: tree-order sums)
+        assert res.path_flags & SPLIT
+        assert_bucket_centroids(got, xyzi_of(out), rep.counts, rep.cells, merged, params.leaf)
+    else:
+        assert_centroids_close_or_exact(got, xyzi_of(out), rep.counts, rep.cells, merged, params.leaf, sequential=False)
+    if not res.bounds_from_crop:
+        assert list(res.min_b) == list(rep.min_b) and list(res.div_b) == list(rep.div_b)
+    return res, rep
+
+
+def needs_lds_rank(res):
+    if not res.path_flags & 1:
+        pytest.skip("the device probe did not find lane-ordered LDS adds: no bucket path on this device")
+
+
+@pytest.mark.parametrize("min_pts", [0, 2])
+def test_stream_of_frames_takes_one_global_pass(min_pts):
+    n_per = 150_000
+    with capi.CloudMerger(max_points_total=4 * n_per, max_sensors=4, flags=capi.FLAG_OCCUPANCY) as cm:
+        flags = []
+        for k in range(4):
+            sensors, params = synth.config2_stream(k, n_per_sensor=n_per, min_pts=min_pts)
+            res, rep = frame_against_oracle(cm, sensors, params, 4 * n_per)
+            needs_lds_rank(res)
+            flags.append(res.path_flags)
+            assert res.path_flags & BUCKET
+        assert not flags[0] & QUANTILE, "the first frame has no predecessor"
+        assert all(f & QUANTILE for f in flags[1:]), flags
+        assert not any(f & REDONE for f in flags[1:]), flags
+        assert res.sort_passes == 1
+
+
+def test_full_size_stream():
+    """cfg2 itself: 4 x 1 M points, 5 cm, min 2 points per voxel — 2048 buckets of about 1950 records."""
+    with capi.CloudMerger(max_points_total=4_000_000, max_sensors=4, flags=capi.FLAG_OCCUPANCY) as cm:
+        for k in range(3):
+            sensors, params = synth.config2_stream(k, min_pts=2)
+            res, rep = frame_against_oracle(cm, sensors, params, 4_000_000)
+            needs_lds_rank(res)
+            assert bool(res.path_flags & QUANTILE) == (k > 0)
+            assert not res.path_flags & REDONE
+        assert res.sort_passes == 1
+
+
+def test_changed_scene_is_handed_back_and_redone():
+    """The splitters are a prediction. A frame whose points sit where the last frame had few overfills a bucket: k4_colscan
+    notices, the frame is redone with the fixed-grid passes (CM_PATH_REDONE, same result), the quantile passes rest and
+    come back with fresh splitters."""
+    n_per = 150_000
+    with capi.CloudMerger(max_points_total=4 * n_per, max_sensors=4, flags=capi.FLAG_OCCUPANCY) as cm:
+        sensors, params = synth.config2_stream(0, n_per_sensor=n_per, min_pts=2)
+        res, _ = frame_against_oracle(cm, sensors, params, 4 * n_per)
+        needs_lds_rank(res)
+        # same poses, same bounds (the corner points keep the predicted box), but nearly everything inside one cubic metre
+        squeezed = []
+        for s in sensors:
+            a = s.data.copy()
+            rng = np.random.default_rng(7)
+            keep = rng.random(s.n) < 0.02
+            for f in ("x", "y", "z"):
+                a[f] = np.where(keep, a[f], (a[f] * np.float32(0.03)).astype(np.float32))
+            squeezed.append(SensorCloud(data=a, n=s.n, q_xyzw=s.q_xyzw, t_xyz=s.t_xyz, point_step=s.point_step,
+                                        off_x=s.off_x, off_y=s.off_y, off_z=s.off_z, off_i=s.off_i))
+        res, _ = frame_against_oracle(cm, squeezed, params, 4 * n_per)
+        assert res.path_flags & REDONE and not res.path_flags & QUANTILE
+        seen_quant = False
+        for k in range(1, 14):
+            sensors, params = synth.config2_stream(k, n_per_sensor=n_per, min_pts=2)
+            res, _ = frame_against_oracle(cm, sensors, params, 4 * n_per)
+            seen_quant = seen_quant or bool(res.path_flags & QUANTILE)
+        assert seen_quant, "the quantile passes come back after their rest"
+
+
+def test_crop_box_frames_use_the_quantile_pass_too():
+    n_per = 200_000
+    with capi.CloudMerger(max_points_total=4 * n_per, max_sensors=4, flags=capi.FLAG_OCCUPANCY) as cm:
+        flags = []
+        for k in range(3):
+            sensors, params = synth.config2_stream(k, n_per_sensor=n_per, min_pts=2)
+            params = MergeParams(leaf=params.leaf, min_points_per_voxel=2, crop_min=(-21.0, -22.0, -23.0), crop_max=(22.0, 21.0, 20.0))
+            res, rep = frame_against_oracle(cm, sensors, params, 4 * n_per)
+            needs_lds_rank(res)
+            flags.append(res.path_flags)
+        assert flags[1] & QUANTILE and flags[2] & QUANTILE, flags
+
+
+def test_switch_off(monkeypatch):
+    monkeypatch.setenv("CM_QUANT", "0")
+    n_per = 100_000
+    with capi.CloudMerger(max_points_total=4 * n_per, max_sensors=4, flags=capi.FLAG_OCCUPANCY) as cm:
+        for k in range(2):
+            sensors, params = synth.config2_stream(k, n_per_sensor=n_per, min_pts=2)
+            res, _ = frame_against_oracle(cm, sensors, params, 4 * n_per)
+            assert not res.path_flags & QUANTILE
