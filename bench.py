@@ -286,7 +286,7 @@ def main():
             c.submit_device(k, dv[k].data_ptr(), s.n, s.point_step, s.off_x, s.off_y, s.off_z, s.off_i)
         c.merge_voxelize_async(cparams)
 
-    stats = {"redone": 0, "packed": 0, "lat": [], "done_t": []}
+    stats = {"redone": 0, "packed": 0, "quantile": 0, "lat": [], "done_t": []}
 
     def run_steps(n, first=0, record=False):
         """n complete frames; at most `inflight` enqueued at any time; every frame's result is waited for."""
@@ -304,6 +304,7 @@ def main():
                 stats["lat"].append(now - t_enq[done]); stats["done_t"].append(now)
                 stats["redone"] += 1 if res.path_flags & capi.PATH_REDONE else 0
                 stats["packed"] += 1 if res.path_flags & capi.PATH_PACKED else 0
+                stats["quantile"] += 1 if res.path_flags & capi.PATH_QUANTILE else 0
             done += 1
         return res
 
@@ -356,7 +357,7 @@ def main():
                               "reaches 30 % further out than the box predicted from its predecessors") if moving else
                              "static: the same frame resubmitted every step",
                    "frames_in_flight": inflight,
-                   "redone_frames": stats["redone"], "packed_frames": stats["packed"],
+                   "redone_frames": stats["redone"], "packed_frames": stats["packed"], "quantile_frames": stats["quantile"],
                    "frame_latency_ms": {"p50": 1e3 * float(lat[len(lat) // 2]), "p99": 1e3 * float(lat[min(len(lat) - 1, int(0.99 * len(lat)))]),
                                         "note": "enqueue -> result count back on the host, with the other frames in flight"},
                    "frame_interval_ms": {"p50": 1e3 * float(gaps[len(gaps) // 2]), "p99": 1e3 * float(gaps[min(len(gaps) - 1, int(0.99 * len(gaps)))])},

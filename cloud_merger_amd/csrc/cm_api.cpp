@@ -171,9 +171,11 @@ struct cm_ctx {
     int32_t spl_min_b[3] = {0, 0, 0}, spl_div_b[3] = {0, 0, 0};   // ... as indices of this grid
     float spl_inv_leaf[3] = {0, 0, 0};
     uint32_t *qcnt = nullptr, *qtot = nullptr, *qbofs = nullptr;  // per-tile bucket counts / prefixes, bucket totals, bucket starts
+    uint16_t* qbid = nullptr;            // the bucket of every padded slot
     bool last_quant = false;             // the frame in flight runs the quantile passes
     bool wrote_spl = false;              // ... and its finish leaves splitters in spl[spl_cur ^ 1]
-    uint32_t quant_off_frames = 0, quant_backoff = 8;   // after a bucket outgrew the finish: fixed-grid passes for a while
+    uint32_t quant_off_frames = 0;       // frames for which the fixed-grid passes run although splitters are at hand
+    uint32_t quant_streak = 0, quant_good = 0;   // hand-backs in a row (a good frame or two between them do not end a row); good frames since
     int lb_grid_mode = 0, lb_mode = 0;   // the last launch_bucket's arguments (a quantile frame that is handed back is
     uint32_t lb_g = 0, lb_low = 0;       // redone with the fixed-grid passes in the same box)
 
@@ -281,7 +283,7 @@ void free_all(cm_ctx* c) {
     F(c->keys_a); F(c->keys_b); F(c->vals_a); F(c->vals_b); F(c->hist); F(c->totals);
     F(c->seg_counts); F(c->seg_tile_counts); F(c->seg_groups); F(c->grp); F(c->partials); F(c->out_key); F(c->out_cnt); F(c->merged_total); F(c->out); F(c->merged); F(c->partial); F(c->table_entries); F(c->mask); F(c->sorted_pts); F(c->rows); F(c->d_state_o);
     F(c->stage32); F(c->out32); F(c->rec_a); F(c->rec_b); F(c->dig); F(c->tile_state); F(c->wave_cnt); F(c->records);
-    F(c->spl[0]); F(c->spl[1]); F(c->qcnt); F(c->qtot); F(c->qbofs);
+    F(c->spl[0]); F(c->spl[1]); F(c->qcnt); F(c->qtot); F(c->qbofs); F(c->qbid);
     F(c->d_ground); F(c->d_state_g); F(c->gmask); F(c->zone_off); F(c->d_planes); F(c->hyp0); F(c->valid0); F(c->counts0); F(c->chunk_sums); F(c->bmask); F(c->zcode);
     F(c->d_frame); F(c->d_tiles); F(c->d_state[0]); F(c->d_state[1]);
     if (c->h_state) (void)hipHostFree(c->h_state);
@@ -525,6 +527,7 @@ int bucket_buffers(cm_ctx* c) {
         if (!p) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&p), (CM4_BINS + 4) * 4));
     if (!c->qcnt) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->qcnt), static_cast<size_t>(std::min<uint32_t>(c->cap_tiles, CM4_MAX_TILES)) * (CM4_BINS / 2) * 4));
     if (!c->qtot) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->qtot), CM4_BINS * 4));
+    if (!c->qbid) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->qbid), static_cast<size_t>(std::min<uint32_t>(c->cap_tiles, CM4_MAX_TILES)) * CM_TILE * 2));
     if (!c->qbofs) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->qbofs), (CM4_BINS + 4) * 4));
     return CM_OK;
 }
@@ -574,12 +577,12 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
         const uint32_t* spl = c->spl[c->spl_cur];
         uint32_t* spl_next = c->spl[c->spl_cur ^ 1];
         prof_mark(c, "k4_hist");
-        cmk4_hist(st, f, c->d_frame, c->d_tiles, do_setup_q, state, spl, c->qcnt, c->tile_state, f.n_padded / 1024 + 2, c->records,
+        cmk4_hist(st, f, c->d_frame, c->d_tiles, do_setup_q, state, spl, c->qcnt, c->qbid, c->tile_state, f.n_padded / 1024 + 2, c->records,
                   grid_mode, predicted ? 1 : 0, nt);
         prof_mark(c, "k4_colscan");
         cmk4_colscan(st, state, c->h_state_dev, c->qcnt, c->qtot, nt, CM4_CAP);
         prof_mark(c, "k4_scatter");
-        cmk4_scatter(st, c->d_frame, c->d_tiles, state, spl, c->qcnt, c->qtot, c->qbofs, nb, c->rec_a, c->records, nt,
+        cmk4_scatter(st, c->d_frame, c->d_tiles, state, c->qbid, c->qcnt, c->qtot, c->qbofs, nb, c->rec_a, c->records, nt,
                      predicted ? 1 : 0, c->d_tile_kept, nt);
         // (tile_info: one word pair per bucket; the group totals of the kept voxels behind them — nb + nb / 128 + 1 <= n_padded / 1024 + 2)
         uint32_t* grp_cnt = reinterpret_cast<uint32_t*>(c->tile_state + nb);
@@ -1088,8 +1091,12 @@ int wait_frame(cm_ctx* c, cm_result* res) {
             const bool quant_fail = c->last_quant && !h0.outside &&
                                     (h0.err == CM_DEV_ERR_QUANT || h0.err == CM_DEV_ERR_UNSORTED || h0.err == CM_DEV_ERR_BUCKET);
             if (quant_fail) {
-                c->quant_off_frames = c->quant_backoff;
-                if (c->quant_backoff < 1024) c->quant_backoff *= 2;
+                // The redone frame leaves the splitters of THIS scene, so the next frame may try at once: one abrupt change costs one
+                // hand-back. Only when hand-backs keep coming (a scene that flips from frame to frame) do the quantile passes rest:
+                // 4, 16, 64, 256 frames.
+                c->quant_off_frames = c->quant_streak ? std::min<uint32_t>(1u << (2 * c->quant_streak), 256u) : 0u;
+                if (c->quant_streak < 8) ++c->quant_streak;
+                c->quant_good = 0;
                 ++c->n_redone;
                 redone = true;
                 c->h_state->err = 0;
@@ -1214,7 +1221,7 @@ int wait_frame(cm_ctx* c, cm_result* res) {
             std::memcpy(c->spl_min_b, c->frame.box_min_b, sizeof c->spl_min_b);
             std::memcpy(c->spl_div_b, c->frame.box_div_b, sizeof c->spl_div_b);
             std::memcpy(c->spl_inv_leaf, c->frame.inv_leaf, sizeof c->spl_inv_leaf);
-            if (c->last_quant && !redone && c->quant_backoff > 8) --c->quant_backoff;
+            if (c->last_quant && !redone && ++c->quant_good >= 8) c->quant_streak = 0;      // eight good frames in a row: the row of hand-backs is over
         }
         if (h.status == CM_OK) {
             r.n_merged = h.n_valid;

@@ -82,11 +82,11 @@ void cmk3_compact(hipStream_t s, const CmFrameState* st, CmFrameState* st_next, 
 // spl: CM4_BINS + 1 splitters (ascending indices, spl[0] = 0, 0xFFFFFFFF beyond the frame's buckets); cnt: n_tiles rows of
 // CM4_BINS 16-bit counters; totals: CM4_BINS words; bofs: CM4_BINS + 1 words (first record of every bucket, total)
 void cmk4_hist(hipStream_t s, const CmFrameDev& f, CmFrameDev* fd, CmTileDev* tiles, bool do_setup, CmFrameState* st,
-               const uint32_t* spl, uint32_t* cnt, unsigned long long* tile_state, uint32_t n_tile_state, float* records,
-               int grid_mode, int check_box, uint32_t n_tiles);
+               const uint32_t* spl, uint32_t* cnt, uint16_t* bid, unsigned long long* tile_state, uint32_t n_tile_state, float* records,
+               int grid_mode, int check_box, uint32_t n_tiles);       // bid: the bucket of every padded slot (0xFFFF: no record)
 void cmk4_colscan(hipStream_t s, CmFrameState* st, uint32_t* host_state, uint32_t* cnt, uint32_t* totals, uint32_t n_tiles,
                   uint32_t cap);
-void cmk4_scatter(hipStream_t s, const CmFrameDev* fd, const CmTileDev* tiles, CmFrameState* st, const uint32_t* spl,
+void cmk4_scatter(hipStream_t s, const CmFrameDev* fd, const CmTileDev* tiles, CmFrameState* st, const uint16_t* bid,
                   const uint32_t* cnt, const uint32_t* totals, uint32_t* bofs, uint32_t n_buckets, void* rec_out,
                   const float* records, uint32_t n_records, int fold, uint32_t* tile_kept, uint32_t n_tiles);
 

@@ -49,17 +49,36 @@ __device__ __forceinline__ uint32_t block_excl_scan4(uint32_t v, uint32_t* lds, 
     return woff + incl - v;
 }
 
-// Bucket of an index: the last splitter <= key. spl: CM4_BINS words in LDS, spl[0] = 0, ascending, 0xFFFFFFFF beyond the
-// frame's buckets (an index is below 2^31: the host only takes this path for key_bits < 32). Eight searches side by side.
-template <int N>
-__device__ __forceinline__ void buckets_of(const uint32_t* __restrict__ spl, const uint32_t (&key)[N], uint32_t (&bk)[N]) {
+// Bucket of an index = the number of splitters S[1 .. CM4_BINS - 1] that are <= key (S[0] = 0 is below every index; S is
+// ascending, 0xFFFFFFFF beyond the frame's buckets; an index is below 2^31: the host only takes this path for key_bits < 32).
+// The splitters sit in LDS as a perfect binary tree in breadth-first order (node i: children 2i + 1, 2i + 2; node of level l,
+// position p = S[(2p + 1) << (10 - l)]): the nodes a wave's lanes read in one step are NEIGHBOURS in memory, so they spread
+// over the banks — the same search over the sorted array reads addresses that are multiples of the step, i.e. ONE bank for
+// every step of 32 or more and a few for the smaller ones (k4_hist 40 us against 19 us for k2_hist0 when it was written
+// that way). Eight searches side by side.
+static_assert(CM4_BINS == 2048, "eleven levels");
+// (nodes numbered from 1, heap fashion: children of node b are 2b and 2b + 1, so a step is b = 2b + (tree[b] <= key) — one
+// add-with-carry behind the compare; word 0 of the tree is unused. After eleven steps b - 2048 is the bucket.)
+__device__ __forceinline__ void load_splitter_tree(uint32_t* __restrict__ tree, const uint32_t* __restrict__ spl_g) {
 #pragma unroll
-    for (int r = 0; r < N; ++r) bk[r] = 0;
-#pragma unroll
-    for (uint32_t step = CM4_BINS / 2; step; step >>= 1) {
-#pragma unroll
-        for (int r = 0; r < N; ++r) bk[r] += (spl[bk[r] + step] <= key[r]) ? step : 0u;
+    for (int q = 0; q < CM4_BINS / CM2_BLOCK; ++q) {
+        const uint32_t e = q * CM2_BLOCK + threadIdx.x;            // node e (1 .. 2047)
+        const uint32_t l = 31u - static_cast<uint32_t>(__builtin_clz(e | 1u));
+        const uint32_t p = e - (1u << l);
+        tree[e] = e ? spl_g[((2u * p + 1u) << (10u - l))] : 0u;
     }
+}
+template <int N>
+__device__ __forceinline__ void buckets_of(const uint32_t* __restrict__ tree, const uint32_t (&key)[N], uint32_t (&bk)[N]) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) bk[r] = 1;
+#pragma unroll
+    for (int l = 0; l < 11; ++l) {
+#pragma unroll
+        for (int r = 0; r < N; ++r) bk[r] = bk[r] + bk[r] + ((tree[bk[r]] <= key[r]) ? 1u : 0u);
+    }
+#pragma unroll
+    for (int r = 0; r < N; ++r) bk[r] -= CM4_BINS;
 }
 
 // The exact bounds of the frame's valid points from the per-tile records (see fold_bounds, cm_kernels_v2.hip).
@@ -111,7 +130,7 @@ __device__ __forceinline__ void fold_bounds4(float* s_f, CmFrameState* __restric
 __global__ __launch_bounds__(CM2_BLOCK) void k4_hist(const CmFrameDev fv, CmFrameDev* __restrict__ fd_dst,
                                                      CmTileDev* __restrict__ tiles_dst, int do_setup,
                                                      CmFrameState* __restrict__ st, const uint32_t* __restrict__ spl_g,
-                                                     uint32_t* __restrict__ cnt,
+                                                     uint32_t* __restrict__ cnt, uint16_t* __restrict__ bid,
                                                      unsigned long long* __restrict__ tile_state, uint32_t n_tile_state,
                                                      float* __restrict__ records, int grid_mode, int check_box) {
     __shared__ uint32_t spl[CM4_BINS];
@@ -158,8 +177,7 @@ __global__ __launch_bounds__(CM2_BLOCK) void k4_hist(const CmFrameDev fv, CmFram
     const CmSensorDev& sd = fd->s[te.info & 0xFFu];
     Pt p[CM2_ITEMS];
     load_tile_te<CM2_ITEMS>(te, sd, w * (64 * CM2_ITEMS) + lane, p);
-#pragma unroll
-    for (int q = 0; q < CM4_BINS / CM2_BLOCK; ++q) spl[q * CM2_BLOCK + threadIdx.x] = spl_g[q * CM2_BLOCK + threadIdx.x];
+    load_splitter_tree(spl, spl_g);
     float m[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) m[k] = sd.m[k];
@@ -196,11 +214,14 @@ __global__ __launch_bounds__(CM2_BLOCK) void k4_hist(const CmFrameDev fv, CmFram
         keepm |= (ok & in) ? (1u << r) : 0u;
     }
     buckets_of<CM2_ITEMS>(spl, key, bk);
+    const uint32_t slot0 = tile * CM_TILE + w * (64 * CM2_ITEMS) + lane;
 #pragma unroll
     for (int r = 0; r < CM2_ITEMS; ++r) {
         // (a slot without a record adds nothing, to a word of its own: same-address LDS adds of a wave serialise)
         const bool keep = (keepm >> r) & 1u;
         atomicAdd(&lh[keep ? bk[r] >> 1 : static_cast<uint32_t>(lane)], (keep ? 1u : 0u) << ((bk[r] & 1u) * 16u));
+        // the bucket of every slot (0xFFFF: no record), so that k4_scatter neither tests nor searches a second time
+        bid[slot0 + r * 64] = static_cast<uint16_t>(keep ? bk[r] : 0xFFFFu);
     }
     if (predicted) {
         cnt_ok = static_cast<uint32_t>(__builtin_popcount(okm));
@@ -257,15 +278,16 @@ __global__ __launch_bounds__(CM2_BLOCK) void k4_hist(const CmFrameDev fv, CmFram
 // bucket beyond the finish's capacity aborts the frame — its packed prefixes may then have carried into their neighbours,
 // and nothing reads them).
 // ------------------------------------------------------------------------------------------------
-#define CM4_SCAN_TPC 24            // tiles per chunk at most: 64 chunks -> 1536 tiles (6.3 M slots)
+#define CM4_SCAN_TPC 12            // tiles per chunk at most: 128 chunks -> 1536 tiles (6.3 M slots)
+static_assert(CM4_SCAN_TPC * 128 >= CM4_MAX_TILES, "k4_colscan's register tile covers the frames the host sends here");
 __global__ __launch_bounds__(1024) void k4_colscan(CmFrameState* __restrict__ st, uint32_t* __restrict__ host_state,
                                                    uint32_t* __restrict__ cnt, uint32_t* __restrict__ totals,
                                                    uint32_t n_tiles, uint32_t cap) {
-    __shared__ uint32_t s_lo[64][17], s_hi[64][17];
+    __shared__ uint32_t s_lo[16][8], s_hi[16][8];
     if (st->status != CM_DEV_OK || st->outside) return;
-    const uint32_t j = threadIdx.x & 15u, c = threadIdx.x >> 4;
-    const uint32_t tpc = (n_tiles + 63u) / 64u;
-    const uint32_t word = blockIdx.x * 16u + j;
+    const uint32_t j = threadIdx.x & 7u, c = threadIdx.x >> 3;
+    const uint32_t tpc = (n_tiles + 127u) / 128u;
+    const uint32_t word = blockIdx.x * 8u + j;
     uint32_t v[CM4_SCAN_TPC];
     uint32_t lo = 0, hi = 0;
 #pragma unroll
@@ -274,10 +296,22 @@ __global__ __launch_bounds__(1024) void k4_colscan(CmFrameState* __restrict__ st
         v[k] = (static_cast<uint32_t>(k) < tpc && t < n_tiles) ? cnt[static_cast<size_t>(t) * (CM4_BINS / 2) + word] : 0u;
         lo += v[k] & 0xFFFFu; hi += v[k] >> 16;
     }
-    s_lo[c][j] = lo; s_hi[c][j] = hi;
+    // prefix over the chunks: eight of them sit in one wave (lanes 8 apart), the sixteen waves meet in LDS
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t ilo = lo, ihi = hi;
+#pragma unroll
+    for (int d = 8; d < 64; d <<= 1) {
+        const uint32_t a = __shfl_up(ilo, d), b2 = __shfl_up(ihi, d);
+        if (lane >= d) { ilo += a; ihi += b2; }
+    }
+    if (lane >= 56) { s_lo[w][j] = ilo; s_hi[w][j] = ihi; }
     __syncthreads();
-    uint32_t plo = 0, phi = 0;
-    for (uint32_t q = 0; q < c; ++q) { plo += s_lo[q][j]; phi += s_hi[q][j]; }
+    uint32_t plo = ilo - lo, phi = ihi - hi;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const uint32_t a = s_lo[q][j], b2 = s_hi[q][j];
+        if (q < w) { plo += a; phi += b2; }
+    }
     uint32_t run = plo | (phi << 16);
 #pragma unroll
     for (int k = 0; k < CM4_SCAN_TPC; ++k) {
@@ -285,7 +319,7 @@ __global__ __launch_bounds__(1024) void k4_colscan(CmFrameState* __restrict__ st
         if (static_cast<uint32_t>(k) < tpc && t < n_tiles) cnt[static_cast<size_t>(t) * (CM4_BINS / 2) + word] = run;
         run += v[k];
     }
-    if (c == 63u) {
+    if (c == 127u) {
         const uint32_t tlo = plo + lo, thi = phi + hi;
         totals[2 * word] = tlo; totals[2 * word + 1] = thi;
         if (tlo > cap || thi > cap) {                      // a bucket the finish cannot hold: the frame goes back
@@ -303,15 +337,15 @@ __global__ __launch_bounds__(1024) void k4_colscan(CmFrameState* __restrict__ st
 // buckets in ascending address order with same-bucket records side by side, which is what lets the XCD's L2 put the
 // 32-byte runs of neighbouring tiles together (file header). Tiles are dealt to the XCDs in contiguous ranges.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(CM2_BLOCK, 4) void k4_scatter(const CmFrameDev* __restrict__ fd, const CmTileDev* __restrict__ tiles,
-                                                           CmFrameState* __restrict__ st, const uint32_t* __restrict__ spl_g,
+__global__ __launch_bounds__(CM2_BLOCK, 6) void k4_scatter(const CmFrameDev* __restrict__ fd, const CmTileDev* __restrict__ tiles,
+                                                           CmFrameState* __restrict__ st, const uint16_t* __restrict__ bid,
                                                            const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ totals,
                                                            uint32_t* __restrict__ bofs, uint32_t n_buckets,
                                                            float4* __restrict__ rec_out, const float* __restrict__ records,
                                                            uint32_t n_records, int fold, uint32_t* __restrict__ tile_kept) {
     constexpr int HW = CM4_BINS / 2;                      // counter words per wave
     constexpr int STG = 2048;                             // staged records per round
-    __shared__ uint32_t buf[STG * 4 + STG / 2];           // splitters | per-wave counters (8 x HW) | staging: records + buckets
+    __shared__ uint32_t buf[STG * 4 + STG / 2];           // per-wave counters (8 x HW) | staging: records + buckets
     __shared__ uint32_t gofs[CM4_BINS];
     __shared__ uint32_t lds[CM2_WAVES];
     static_assert(CM2_WAVES * HW <= STG * 4 + STG / 2 && CM4_BINS <= STG * 4, "overlays fit");
@@ -330,30 +364,27 @@ __global__ __launch_bounds__(CM2_BLOCK, 4) void k4_scatter(const CmFrameDev* __r
         const uint32_t per = gridDim.x / 8;              // contiguous tile range per XCD
         if (blockIdx.x < per * 8) tile = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
     }
-    const BoxGrid b = box_grid_of(fd);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 
     const CmTileDev te = tiles[tile];
     const uint32_t sidx = te.info & 0xFFu;
     Pt p[CM2_ITEMS];
     load_tile_te<CM2_ITEMS, true>(te, fd->s[sidx], w * (64 * CM2_ITEMS) + lane, p);     // (non-temporal: the last reader of the raw clouds)
+    uint32_t bk[CM2_ITEMS];                               // k4_hist left every slot's bucket (0xFFFF: the slot holds no record)
+    {
+        const uint32_t slot0 = tile * CM_TILE + w * (64 * CM2_ITEMS) + lane;
 #pragma unroll
-    for (int q = 0; q < CM4_BINS / CM2_BLOCK; ++q) buf[q * CM2_BLOCK + threadIdx.x] = spl_g[q * CM2_BLOCK + threadIdx.x];
+        for (int r = 0; r < CM2_ITEMS; ++r) bk[r] = bid[slot0 + r * 64];
+    }
+    for (uint32_t q = threadIdx.x; q < CM2_WAVES * HW; q += CM2_BLOCK) buf[q] = 0;
 
     float4 rec[CM2_ITEMS];
-    uint32_t key[CM2_ITEMS], bk[CM2_ITEMS];
     uint32_t vmask = 0;
     {
         const CmSensorDev& sd = fd->s[sidx];
         float m[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) m[k] = sd.m[k];
-        const uint32_t crop = fd->crop_enable;
-        float cmn0 = 0.f, cmn1 = 0.f, cmn2 = 0.f, cmx0 = 0.f, cmx1 = 0.f, cmx2 = 0.f;
-        if (crop) {
-            cmn0 = fd->crop_min[0]; cmn1 = fd->crop_min[1]; cmn2 = fd->crop_min[2];
-            cmx0 = fd->crop_max[0]; cmx1 = fd->crop_max[1]; cmx2 = fd->crop_max[2];
-        }
         const bool all_fields = fd->downsample_all != 0;
 #pragma unroll
         for (int r = 0; r < CM2_ITEMS; ++r) {
@@ -361,19 +392,10 @@ __global__ __launch_bounds__(CM2_BLOCK, 4) void k4_scatter(const CmFrameDev* __r
             rec[r].y = xf_row(m[4], m[5], m[6], m[7], p[r].x, p[r].y, p[r].z);
             rec[r].z = xf_row(m[8], m[9], m[10], m[11], p[r].x, p[r].y, p[r].z);
             rec[r].w = all_fields ? p[r].i : 0.f;
-            bool ok = finite_f32(rec[r].x) & finite_f32(rec[r].y) & finite_f32(rec[r].z);
-            if (crop) ok = ok & !((rec[r].x < cmn0) | (rec[r].x > cmx0) | (rec[r].y < cmn1) | (rec[r].y > cmx1) |
-                                  (rec[r].z < cmn2) | (rec[r].z > cmx2));
-            bool in;
-            key[r] = key_of(b, rec[r].x, rec[r].y, rec[r].z, &in);
-            ok = ok & in;
-            vmask |= ok ? (1u << r) : 0u;
+            vmask |= (bk[r] != 0xFFFFu) ? (1u << r) : 0u;
+            bk[r] &= CM4_BINS - 1;
         }
     }
-    __syncthreads();                                       // the splitters are in LDS
-    buckets_of<CM2_ITEMS>(buf, key, bk);
-    __syncthreads();                                       // ... and read: their words become the counters
-    for (uint32_t q = threadIdx.x; q < CM2_WAVES * HW; q += CM2_BLOCK) buf[q] = 0;
     __syncthreads();
     // this tile's row of the column prefix and the bucket totals: asked for now, used behind the ranking
     const uint2 trow = *reinterpret_cast<const uint2*>(cnt + static_cast<size_t>(tile) * HW + 2 * threadIdx.x);
@@ -463,18 +485,18 @@ __global__ __launch_bounds__(CM2_BLOCK, 4) void k4_scatter(const CmFrameDev* __r
 }  // namespace
 
 void cmk4_hist(hipStream_t s, const CmFrameDev& f, CmFrameDev* fd, CmTileDev* tiles, bool do_setup, CmFrameState* st,
-               const uint32_t* spl, uint32_t* cnt, unsigned long long* tile_state, uint32_t n_tile_state, float* records,
+               const uint32_t* spl, uint32_t* cnt, uint16_t* bid, unsigned long long* tile_state, uint32_t n_tile_state, float* records,
                int grid_mode, int check_box, uint32_t n_tiles) {
-    hipLaunchKernelGGL(k4_hist, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, f, fd, tiles, do_setup ? 1 : 0, st, spl, cnt, tile_state,
+    hipLaunchKernelGGL(k4_hist, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, f, fd, tiles, do_setup ? 1 : 0, st, spl, cnt, bid, tile_state,
                        n_tile_state, records, grid_mode, check_box);
 }
 void cmk4_colscan(hipStream_t s, CmFrameState* st, uint32_t* host_state, uint32_t* cnt, uint32_t* totals, uint32_t n_tiles,
                   uint32_t cap) {
-    hipLaunchKernelGGL(k4_colscan, dim3(CM4_BINS / 32), dim3(1024), 0, s, st, host_state, cnt, totals, n_tiles, cap);
+    hipLaunchKernelGGL(k4_colscan, dim3(CM4_BINS / 16), dim3(1024), 0, s, st, host_state, cnt, totals, n_tiles, cap);
 }
-void cmk4_scatter(hipStream_t s, const CmFrameDev* fd, const CmTileDev* tiles, CmFrameState* st, const uint32_t* spl,
+void cmk4_scatter(hipStream_t s, const CmFrameDev* fd, const CmTileDev* tiles, CmFrameState* st, const uint16_t* bid,
                   const uint32_t* cnt, const uint32_t* totals, uint32_t* bofs, uint32_t n_buckets, void* rec_out,
                   const float* records, uint32_t n_records, int fold, uint32_t* tile_kept, uint32_t n_tiles) {
-    hipLaunchKernelGGL(k4_scatter, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, spl, cnt, totals, bofs, n_buckets,
+    hipLaunchKernelGGL(k4_scatter, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, bid, cnt, totals, bofs, n_buckets,
                        reinterpret_cast<float4*>(rec_out), records, n_records, fold, tile_kept);
 }

@@ -657,10 +657,13 @@ def test_crop_heavy_frames_pack_the_survivors(sort_path, outlier):
         assert not any(flags)
 
 
-def test_predicted_box_miss_is_redone_and_learned(sort_path):
+def test_predicted_box_miss_is_redone_and_learned(sort_path, monkeypatch):
     """No crop box: the bucket path sorts in the previous frame's bounds plus a margin. A frame whose
     cloud leaves that box is found out on the device and redone at once — on the bucket path again, in a
-    box around the exact bounds the failed attempt measured (same answer) — and the box follows."""
+    box around the exact bounds the failed attempt measured (same answer) — and the box follows.
+    (CM_QUANT=0: with the quantile passes on, the last frame — the near cloud sorted at the far cloud's quantiles — is
+    handed back as well, for another reason; tests/test_quantile.py covers that.)"""
+    monkeypatch.setenv("CM_QUANT", "0")
     rng = np.random.default_rng(5)
     near = [xyzi_cloud(rng.uniform(-5, 5, (40_000, 3)), rng.uniform(0, 100, 40_000))]
     far = [xyzi_cloud(rng.uniform(-40, 60, (40_000, 3)), rng.uniform(0, 100, 40_000))]
