@@ -56,7 +56,8 @@ def parse():
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
                     help="2: headline (BASELINE.json configs[1]); 3: configs[2]; 5: configs[4], the single fused cloud — the "
                          "16 sensors dealt to the ranks, partial tables all-gathered (RCCL), merged on every rank")
-    ap.add_argument("--points-per-sensor", type=int, default=0, help="config 5 only: points per sensor (default 4 M)")
+    ap.add_argument("--points-per-sensor", type=int, default=0, help="points per sensor (default: the configuration's own — 1 M for "
+                    "config 2, 4 M for config 5); anything else is a rehearsal, not BASELINE.json's workload (said so in config.workload)")
     ap.add_argument("--check", action="store_true", help="config 5 only: compare the fused cloud with the CPU oracle on rank 0 "
                                                           "(builds all 16 sensors there: reduced sizes only)")
     ap.add_argument("--min-pts", type=int, default=2, help="min points per voxel (reference: 2, PCL default: 0)")
@@ -235,12 +236,16 @@ def main():
     moving = not args.static and args.config == 2
     frames = []
     if args.config == 2:
+        nps2 = args.points_per_sensor or 1_000_000
         workload = "cfg2: 4 x 1M XYZI float32 points, random SE(3) per sensor, 5 cm voxel, no crop"
+        if nps2 != 1_000_000:
+            workload = f"REHEARSAL (not BASELINE.json's size): cfg2's scene with 4 x {nps2} points, random SE(3) per sensor, 5 cm voxel, no crop"
         for k in range(K):
-            frames.append(synth.config2_stream(k + 97 * rank, min_pts=args.min_pts)[0] if moving else
-                          synth.config2(min_pts=args.min_pts)[0])
+            frames.append(synth.config2_stream(k + 97 * rank, n_per_sensor=nps2, min_pts=args.min_pts)[0] if moving else
+                          synth.config2(n_per_sensor=nps2, min_pts=args.min_pts)[0])
         params = synth.config2(n_per_sensor=8, min_pts=args.min_pts)[1]
-        wide = synth.config2_stream(1000 + rank, min_pts=args.min_pts, wide=True)[0] if (moving and args.jump_every) else None
+        wide = (synth.config2_stream(1000 + rank, n_per_sensor=nps2, min_pts=args.min_pts, wide=True)[0]
+                if (moving and args.jump_every) else None)
     else:
         gen = synth.config3_dense if args.dense else synth.config3
         workload = ("cfg3 (dense variant): 8 x 2M XYZI float32 points drawn inside the reference ROI (86 % survive the crop), "

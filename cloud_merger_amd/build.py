@@ -13,6 +13,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcloudmerge_hip.so")
+# The test build: the same sources with -DCM_TEST_HOOKS (a hook that makes a global pass mis-rank two records, so that the
+# finish's order check can be tested). Loaded only by the one test that asks for it (CM_LIB_VARIANT=testhooks); the
+# shipped library holds no such code.
+HOOKS_LIB_PATH = os.path.join(LIB_DIR, "libcloudmerge_hip_testhooks.so")
 SOURCES = ["cm_kernels.hip", "cm_kernels_v2.hip", "cm_kernels_v3.hip", "cm_kernels_v4.hip", "cm_kernels_ground.hip", "cm_api.cpp"]
 HEADERS = ["cm_device.h", "cm_kernels.h", "cm_common.hpp", os.path.join("..", "..", "include", "cloudmerge.h")]
 
@@ -30,19 +34,23 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def needs_build():
-    if not os.path.exists(LIB_PATH):
+def needs_build(path=None):
+    path = path or LIB_PATH
+    if not os.path.exists(path):
         return True
-    t = os.path.getmtime(LIB_PATH)
+    t = os.path.getmtime(path)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, save_temps=False, verbose=False):
-    if not force and not needs_build():
-        return LIB_PATH
+def build(force=False, save_temps=False, verbose=False, test_hooks=False):
+    out = HOOKS_LIB_PATH if test_hooks else LIB_PATH
+    if not force and not needs_build(out):
+        return out
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc()] + FLAGS + ["-I", CSRC, "-o", LIB_PATH]
+    cmd = [hipcc()] + FLAGS + ["-I", CSRC, "-o", out]
+    if test_hooks:
+        cmd += ["-DCM_TEST_HOOKS"]
     if os.environ.get("CM_PHASE_TIMING") == "1":       # experiment build: scripts/phase_times.py (never the shipped one)
         cmd += ["-DCM_PHASE_TIMING"]
     if save_temps:
@@ -55,11 +63,12 @@ def build(force=False, save_temps=False, verbose=False):
     r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("hipcc failed building libcloudmerge_hip.so")
+        raise RuntimeError("hipcc failed building " + os.path.basename(out))
     if verbose or save_temps:
         sys.stderr.write(r.stderr)
-    return LIB_PATH
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, verbose=True,
+                test_hooks="--test-hooks" in sys.argv))

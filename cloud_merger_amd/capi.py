@@ -125,10 +125,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise OSError(f"{LIB_PATH} is missing: build it with `python -m cloud_merger_amd.build` "
+    path = LIB_PATH
+    if os.environ.get("CM_LIB_VARIANT") == "testhooks":      # the test build (python -m cloud_merger_amd.build --test-hooks)
+        path = os.path.join(HERE, "lib", "libcloudmerge_hip_testhooks.so")
+    if not os.path.exists(path):
+        raise OSError(f"{path} is missing: build it with `python -m cloud_merger_amd.build` "
                       "(the path has no fallback implementation)")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
     L.cm_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(Limits)]
     L.cm_destroy.argtypes = [vp]
@@ -232,6 +235,7 @@ class CloudMerger:
             self._ctx = None
             raise CloudMergeError(st, "cm_create")
         self.flags = flags
+        self.max_points_total = int(max_points_total)
         self._keep = {}
 
     def close(self):

@@ -76,7 +76,7 @@ struct cm_ctx {
     int finish_mode = 0;                 // CM_FINISH: 0 k3_local + k3_compact, 2 (CM_FINISH=v2) k2_local with its look-back
     void* stage32 = nullptr;             // k3_local's staging for partial tables (32-byte entries)
     void* out32 = nullptr;               // the result as pcl::PointXYZI images (cm_result_copy with point_step_out 32)
-    int debug_misrank = 0;               // CM_DEBUG_MISRANK=1 (tests): the last global pass swaps two records of tile 0
+    int debug_misrank = 0;               // test build (CM_TEST_HOOKS) + CM_DEBUG_MISRANK=1: the last global pass swaps two records of tile 0
     float* partials = nullptr;
     uint32_t *out_key = nullptr, *out_cnt = nullptr, *merged_total = nullptr;
     void* out = nullptr;
@@ -1347,7 +1347,9 @@ int cm_create(cm_ctx** out, int device, const cm_limits* lim) {
         }
     }
     if (const char* fm = getenv("CM_FINISH")) c->finish_mode = std::strcmp(fm, "v2") == 0 ? 2 : 0;
+#ifdef CM_TEST_HOOKS                     // (the test build only: python -m cloud_merger_amd.build --test-hooks; never the shipped library)
     if (const char* dm = getenv("CM_DEBUG_MISRANK")) c->debug_misrank = dm[0] == '1' ? 1 : 0;
+#endif
     if (const char* qm = getenv("CM_QUANT")) c->quant_mode = qm[0] == '0' ? 1 : 0;     // CM_QUANT=0: fixed-grid passes only
     if (!ok) {
         free_all(c);

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __r
                                                            const float4* __restrict__ compact_in,
                                                            const uint32_t* __restrict__ wave_cnt, int debug_swap,
                                                            uint32_t* __restrict__ tile_kept) {
-    // debug_swap (tests only, CM_DEBUG_MISRANK=1): the first and the last record of tile 0's sorted tile change places on
+    // debug_swap (the CM_TEST_HOOKS build only, with CM_DEBUG_MISRANK=1): the first and the last record of tile 0's sorted tile change places on
     // their way out — what a mis-ranked pass would look like to the finish, which must notice (CM_DEV_ERR_UNSORTED).
     // 37 KB of LDS and at most 64 VGPRs: four workgroups per CU, so that the 977 tiles of a 4 M-point frame are all
     // resident at once (with three per CU the last 209 tiles ran as a second, nearly empty generation)
@@ -613,6 +613,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __r
                 const float4 r4 = srec[t - lo];
                 const uint32_t dd = sdig[t - lo];
                 uint32_t pos = gofs[dd & 0xFFu] + t;
+#ifdef CM_TEST_HOOKS
                 if (debug_swap && tile == 0 && h == 0 && tile_valid > 1) {
                     const uint32_t last = min(tile_valid, static_cast<uint32_t>(CM_TILE / 2)) - 1u;   // (both in the first staging round)
                     if (t == 0 || t == last) {
@@ -620,6 +621,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __r
                         pos = gofs[sdig[to] & 0xFFu] + to;
                     }
                 }
+#endif
                 rec_out[pos] = r4;
                 if (next_shift < 32u) dig_out[pos] = static_cast<unsigned char>(dd >> 8);
             }

@@ -140,19 +140,25 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
     const uint32_t q_hi = QUANT ? min(SCAL(spl[tile + 1]), fd->box_key_bits < 32u ? (1u << fd->box_key_bits) : 0xFFFFFFFFu) : 0u;
     bool q_bad = false;
     if (QUANT) {
-        float4 r4[LITEMS];
+        // (a bucket holds about 1950 records: four rounds of the workgroup, then — rarely — up to four more)
+        constexpr int HALF = LITEMS / 2;
 #pragma unroll
-        for (int r = 0; r < LITEMS; ++r) {
-            const uint32_t q = r * LBLOCK + threadIdx.x;
-            r4[r] = (q < nom) ? rec[base + q] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1 && nom <= static_cast<uint32_t>(HALF * LBLOCK)) break;     // (uniform)
+            float4 r4[HALF];
 #pragma unroll
-        for (int r = 0; r < LITEMS; ++r) {
-            const uint32_t q = r * LBLOCK + threadIdx.x;
-            if (q < nom) {
-                const uint32_t k = key_of(b, r4[r]);
-                sk[q] = k;
-                q_bad = q_bad || k < q_lo || k >= q_hi;          // (the scatter put a record into a bucket that is not its own)
+            for (int r = 0; r < HALF; ++r) {
+                const uint32_t q = (h * HALF + r) * LBLOCK + threadIdx.x;
+                r4[r] = (q < nom) ? rec[base + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int r = 0; r < HALF; ++r) {
+                const uint32_t q = (h * HALF + r) * LBLOCK + threadIdx.x;
+                if (q < nom) {
+                    const uint32_t k = key_of(b, r4[r]);
+                    sk[q] = k;
+                    q_bad = q_bad || k < q_lo || k >= q_hi;      // (the scatter put a record into a bucket that is not its own)
+                }
             }
         }
         if (threadIdx.x == 0) { s_keyprev = 0u; s_a = 0u; s_bad = 0u; s_njobs = 0u; }

@@ -34,23 +34,44 @@ def allreduce_bounds(dist, mn, mx, n_valid, device="cpu"):
     return np.concatenate([lo, hi]).astype(np.float32)
 
 
-def allgather_tables(dist, table, n_entries, world):
-    """table: int32 tensor [capacity >= n_entries, 8] (cm_partial_entry rows) on this rank's device.
-    Exchanges the lengths first, pads to the longest table, all-gathers once.
+class _DeviceWords:
+    """n int32 words of device memory at `ptr`, for torch.as_tensor (zero-copy through __cuda_array_interface__)."""
+
+    def __init__(self, ptr, n_words):
+        self.__cuda_array_interface__ = {"shape": (int(n_words),), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
+
+
+def alias_device_words(ptr, n_words, device):
+    """A torch int32 tensor over device memory the library owns (no copy); None if this torch build cannot do that."""
+    import torch
+    try:
+        t = torch.as_tensor(_DeviceWords(ptr, n_words), device=device)
+        return t if t.data_ptr() == int(ptr) else None
+    except Exception:            # noqa: BLE001  (any refusal: the caller stages a copy instead)
+        return None
+
+
+def allgather_tables(dist, table, n_entries, world, send_view=None):
+    """table: int32 tensor [capacity >= n_entries, 8] (cm_partial_entry rows) on this rank's device, or None when
+    send_view is given. Exchanges the lengths first, then all-gathers the tables padded to the longest.
+    send_view(max_n): a tensor of max_n rows that STARTS with this rank's table (the library's own buffer, aliased: no
+    staging copy) or None when the buffer is shorter than max_n rows.
     Returns (gathered [world, max_n, 8] tensor, list of lengths)."""
     import torch
-    dev = table.device
+    dev = table.device if table is not None else send_view.device
     mine = torch.tensor([int(n_entries)], dtype=torch.int64, device=dev)
     lens = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(lens, mine)
     counts = [int(v.item()) for v in lens]
     max_n = max(max(counts), 1)
-    send = torch.zeros((max_n, ENTRY_WORDS), dtype=torch.int32, device=dev)
-    if n_entries:
-        send[:n_entries] = table[:n_entries]
+    send = send_view(max_n) if send_view is not None else None
+    if send is None:
+        send = torch.zeros((max_n, ENTRY_WORDS), dtype=torch.int32, device=dev)
+        if n_entries:
+            send[:n_entries] = table[:n_entries] if table is not None else send_view.stage(n_entries)
     if dev.type == "cuda" and hasattr(dist, "all_gather_into_tensor"):
         gathered = torch.empty((world, max_n, ENTRY_WORDS), dtype=torch.int32, device=dev)
-        dist.all_gather_into_tensor(gathered.view(-1), send.view(-1))
+        dist.all_gather_into_tensor(gathered.view(-1), send.reshape(-1))
     else:
         parts = [torch.empty_like(send) for _ in range(world)]
         dist.all_gather(parts, send)
@@ -116,28 +137,53 @@ def fused_cloud(cm, params, dist, rank, world, device, host_exchange=False, time
     if any_bad:
         raise err if err is not None else CloudMergeError(status if bad else -5, "fused_cloud: another rank's partial table failed")
     n = int(part.n_out) if part.status == 0 else 0
-    # (torch.empty, and nothing of torch's pending on the buffer: the library copies on ITS stream, which need not be
-    # torch's — a zero-fill still queued on torch's stream would race with that copy)
-    table = torch.empty((max(n, 1), ENTRY_WORDS), dtype=torch.int32, device=device)
-    torch.cuda.synchronize(device)
-    if n:
-        cm.partial_to_device(table.data_ptr(), n)
-    else:
-        table.zero_()
-    torch.cuda.synchronize(device)
     t1 = time.perf_counter()
-    if world > 1:
-        gathered, counts = allgather_tables(dist, table.to(xdev) if host_exchange else table, n, world)
-        if host_exchange:
-            gathered = gathered.to(device)
-    else:
-        gathered, counts = table.unsqueeze(0), [n]
-    torch.cuda.synchronize(device)
+    # The table stays where cm_merge_partial left it (the library's buffer: one entry per padded input slot at least). On a
+    # device exchange it is sent from there — aliased as a torch tensor, no staging copy — and the collective is ordered
+    # behind the library's kernels by the stream both are enqueued on (cm.set_stream(torch's current stream): the caller's
+    # job, as in bench.py); nothing waits on the host between the table, the all-gather and the merge.
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if not host_exchange else None
+    ptr, n_lib = cm.partial_device() if n else (0, 0)
+    cap_rows = int(cm.max_points_total)
+    if world > 1 and not host_exchange:
+        class _View:
+            device = torch.device(device)
+
+            def __call__(self, max_n):
+                if not n or max_n > cap_rows:
+                    return None
+                a = alias_device_words(ptr, max_n * ENTRY_WORDS, device)
+                return None if a is None else a.view(max_n, ENTRY_WORDS)
+
+            @staticmethod
+            def stage(n_rows):
+                tmp = torch.empty((n_rows, ENTRY_WORDS), dtype=torch.int32, device=device)
+                cm.partial_to_device(tmp.data_ptr(), n_rows)
+                return tmp
+        ev[0].record()
+        gathered, counts = allgather_tables(dist, None, n, world, send_view=_View())
+        ev[1].record()
+        ptrs = [gathered[r].data_ptr() for r in range(world)]
+    elif world > 1:                                # the gloo rehearsal: device -> host -> all-gather -> device
+        host = torch.from_numpy(cm.partial(n).view(np.int32).reshape(-1, ENTRY_WORDS).copy()) if n else \
+            torch.zeros((1, ENTRY_WORDS), dtype=torch.int32)
+        gathered, counts = allgather_tables(dist, host, n, world)
+        gathered = gathered.to(device)
+        torch.cuda.current_stream(device).synchronize()
+        ptrs = [gathered[r].data_ptr() for r in range(world)]
+    else:                                          # one rank: its own table, in place
+        counts = [n]
+        if n:
+            ptrs = [ptr]
+        else:
+            gathered = torch.zeros((1, ENTRY_WORDS), dtype=torch.int32, device=device)
+            torch.cuda.current_stream(device).synchronize()
+            ptrs = [gathered.data_ptr()]
     t2 = time.perf_counter()
-    ptrs = [gathered[r].data_ptr() for r in range(world)]
-    res = cm.merge_tables(ptrs, counts, params)
+    res = cm.merge_tables(ptrs, counts, params)        # (blocking: it returns the merged cloud's counts)
     t3 = time.perf_counter()
     if times is not None:
-        times.update(partial_ms=1e3 * (t1 - t0), exchange_ms=1e3 * (t2 - t1), merge_ms=1e3 * (t3 - t2),
-                     table_entries=n, gathered_entries=int(sum(counts)))
+        x_ms = ev[0].elapsed_time(ev[1]) if (ev is not None and world > 1) else 0.0   # the all-gather on the device
+        times.update(partial_ms=1e3 * (t1 - t0), exchange_ms=1e3 * (t2 - t1) + x_ms,
+                     merge_ms=max(0.0, 1e3 * (t3 - t2) - x_ms), table_entries=n, gathered_entries=int(sum(counts)))
     return res

@@ -23,6 +23,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <sys/stat.h>
+#include <ctime>
 #include <thread>
 #include <vector>
 
@@ -46,6 +48,7 @@ int main(int argc, char** argv) {
     float leaf = 0.01f;
     uint64_t seed = 5001;
     std::string rendezvous = "/tmp/cm_fused.id";
+    unsigned long long run_id = 0;                     // --run-id: the same number on every rank of ONE run (0: not checked)
     for (int a = 1; a < argc; ++a) {
         const std::string k = argv[a];
         auto next = [&]() { if (a + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", k.c_str()); std::exit(2); } return argv[++a]; };
@@ -59,6 +62,7 @@ int main(int argc, char** argv) {
         else if (k == "--steps") steps = std::atoi(next());
         else if (k == "--seed") seed = static_cast<uint64_t>(std::atoll(next()));
         else if (k == "--rendezvous") rendezvous = next();
+        else if (k == "--run-id") run_id = std::strtoull(next(), nullptr, 10);
         else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
     }
     if (world < 1 || world > CM_MAX_SENSORS || rank < 0 || rank >= world || n_sensors < 1 || n_sensors > CM_MAX_SENSORS) {
@@ -68,24 +72,38 @@ int main(int argc, char** argv) {
     if (device < 0) device = rank;
     HIPCHECK(hipSetDevice(device));
 
-    // ---- rendezvous: rank 0 publishes the communicator id through a file (written under a temporary name, then renamed)
-    ncclUniqueId id;
+    // ---- rendezvous: rank 0 publishes {run id, communicator id} through a file (written under a temporary name, then
+    // renamed). A file left by an earlier run must not be taken for this run's: rank 0 removes whatever is there before it
+    // asks for an id (and removes its own file when it leaves); the other ranks only accept a file that carries their --run-id
+    // (when one was given) and that was written after they started (less a grace period for ranks started by hand).
+    struct Hello { unsigned long long run_id; ncclUniqueId id; };
+    Hello hello{};
+    const time_t t_start = std::time(nullptr);
     if (rank == 0) {
-        NCCLCHECK(ncclGetUniqueId(&id));
+        std::remove(rendezvous.c_str());
+        hello.run_id = run_id;
+        NCCLCHECK(ncclGetUniqueId(&hello.id));
         const std::string tmp = rendezvous + ".tmp";
         FILE* f = std::fopen(tmp.c_str(), "wb");
-        if (!f || std::fwrite(&id, sizeof id, 1, f) != 1) { std::fprintf(stderr, "cannot write %s\n", tmp.c_str()); return 1; }
+        if (!f || std::fwrite(&hello, sizeof hello, 1, f) != 1) { std::fprintf(stderr, "cannot write %s\n", tmp.c_str()); return 1; }
         std::fclose(f);
         if (std::rename(tmp.c_str(), rendezvous.c_str()) != 0) { std::fprintf(stderr, "cannot publish %s\n", rendezvous.c_str()); return 1; }
     } else {
         bool ok = false;
         for (int tries = 0; tries < 600 && !ok; ++tries) {
-            FILE* f = std::fopen(rendezvous.c_str(), "rb");
-            if (f) { ok = std::fread(&id, sizeof id, 1, f) == 1; std::fclose(f); }
+            struct stat sb;
+            if (stat(rendezvous.c_str(), &sb) == 0 && sb.st_mtime + 30 >= t_start) {
+                FILE* f = std::fopen(rendezvous.c_str(), "rb");
+                if (f) {
+                    ok = std::fread(&hello, sizeof hello, 1, f) == 1 && (run_id == 0 || hello.run_id == run_id);
+                    std::fclose(f);
+                }
+            }
             if (!ok) std::this_thread::sleep_for(std::chrono::milliseconds(100));
         }
-        if (!ok) { std::fprintf(stderr, "rank %d: no communicator id at %s\n", rank, rendezvous.c_str()); return 1; }
+        if (!ok) { std::fprintf(stderr, "rank %d: no communicator id of this run at %s\n", rank, rendezvous.c_str()); return 1; }
     }
+    const ncclUniqueId id = hello.id;
     ncclComm_t comm;
     NCCLCHECK(ncclCommInitRank(&comm, world, id, rank));
     hipStream_t stream;
@@ -126,53 +144,88 @@ int main(int argc, char** argv) {
     p.crop_enable = 1;
     for (int a = 0; a < 3; ++a) { p.crop_min[a] = cmin[a]; p.crop_max[a] = cmax[a]; }
 
+    // Per step every rank sends {table length, error word}: a rank whose cm_merge_partial / cm_merge_tables failed says so in
+    // the exchange every rank takes part in anyway, and all ranks leave together instead of the others waiting in an
+    // all-gather for ever. A HIP / RCCL failure inside the loop aborts the communicator (the peers' collectives then fail
+    // instead of hanging).
+#define STEP_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "rank %d: %s: %s\n", rank, #x, hipGetErrorString(e_)); (void)ncclCommAbort(comm); return 1; } } while (0)
+#define STEP_NCCL(x) do { ncclResult_t e_ = (x); if (e_ != ncclSuccess) { std::fprintf(stderr, "rank %d: %s: %s\n", rank, #x, ncclGetErrorString(e_)); (void)ncclCommAbort(comm); return 1; } } while (0)
     unsigned long long *d_len = nullptr, *d_lens = nullptr;
-    HIPCHECK(hipMalloc(reinterpret_cast<void**>(&d_len), 8));
-    HIPCHECK(hipMalloc(reinterpret_cast<void**>(&d_lens), 8 * static_cast<size_t>(world)));
+    HIPCHECK(hipMalloc(reinterpret_cast<void**>(&d_len), 16));
+    HIPCHECK(hipMalloc(reinterpret_cast<void**>(&d_lens), 16 * static_cast<size_t>(world)));
     void *send = nullptr, *gathered = nullptr;
     size_t send_cap = 0, gathered_cap = 0;
+    // entries the library's own table buffer holds at least (one per padded input slot): up to that many the table is sent
+    // from where cm_merge_partial left it, without a staging copy
+    const uint64_t own_cap = mine.empty() ? 0 : static_cast<uint64_t>(mine.size()) * ((static_cast<uint64_t>(n_points) + 4095) / 4096 * 4096);
     cm_result res{};
     double t_partial = 0, t_exchange = 0, t_merge = 0;
+    hipEvent_t ev_x0, ev_x1;
+    HIPCHECK(hipEventCreate(&ev_x0));
+    HIPCHECK(hipEventCreate(&ev_x1));
+    unsigned long long my_err = 0;
+    int failed_rank = -1;
     const auto t_all0 = std::chrono::steady_clock::now();
-    for (int it = 0; it < steps; ++it) {
+    for (int it = 0; it <= steps; ++it) {                    // (one exchange more than steps: the last merge's error word)
         const auto t0 = std::chrono::steady_clock::now();
-        for (size_t k = 0; k < mine.size(); ++k)
-            CMCHECK(cm_submit_cloud_device(ctx, static_cast<uint32_t>(k), dev_clouds[k], n_points, 16, 0, 4, 8, 12));
         cm_result part{};
         uint64_t n_mine = 0;
         const void* d_table = nullptr;
-        if (!mine.empty()) {
-            CMCHECK(cm_merge_partial(ctx, &p, nullptr, &part));
-            CMCHECK(cm_partial_device(ctx, &d_table, &n_mine));
+        if (it < steps && !my_err) {
+            for (size_t k = 0; k < mine.size() && !my_err; ++k)
+                if (cm_submit_cloud_device(ctx, static_cast<uint32_t>(k), dev_clouds[k], n_points, 16, 0, 4, 8, 12) < 0) my_err = 1;
+            if (!mine.empty() && !my_err) {
+                if (cm_merge_partial(ctx, &p, nullptr, &part) < 0 || cm_partial_device(ctx, &d_table, &n_mine) < 0) my_err = 2;
+            }
+            if (my_err) std::fprintf(stderr, "rank %d: %s\n", rank, cm_last_error(ctx));
         }
         const auto t1 = std::chrono::steady_clock::now();
-        // lengths first, then the tables padded to the longest (one all-gather each; xGMI is a full mesh: every GPU pushes
-        // its table on all links at once)
-        const unsigned long long len = n_mine;
-        HIPCHECK(hipMemcpyAsync(d_len, &len, 8, hipMemcpyHostToDevice, stream));
-        NCCLCHECK(ncclAllGather(d_len, d_lens, 1, ncclUint64, comm, stream));
-        std::vector<unsigned long long> lens(static_cast<size_t>(world));
-        HIPCHECK(hipMemcpyAsync(lens.data(), d_lens, 8 * static_cast<size_t>(world), hipMemcpyDeviceToHost, stream));
-        HIPCHECK(hipStreamSynchronize(stream));
+        const unsigned long long hello2[2] = {my_err ? 0ull : n_mine, my_err};
+        STEP_HIP(hipMemcpyAsync(d_len, hello2, 16, hipMemcpyHostToDevice, stream));
+        STEP_NCCL(ncclAllGather(d_len, d_lens, 2, ncclUint64, comm, stream));
+        std::vector<unsigned long long> lens2(2 * static_cast<size_t>(world));
+        STEP_HIP(hipMemcpyAsync(lens2.data(), d_lens, 16 * static_cast<size_t>(world), hipMemcpyDeviceToHost, stream));
+        STEP_HIP(hipStreamSynchronize(stream));
+        for (int r = 0; r < world; ++r) if (lens2[2 * r + 1] && failed_rank < 0) failed_rank = r;
+        if (failed_rank >= 0 || it == steps) break;             // every rank sees the same words: all leave together
         unsigned long long max_n = 1;
-        for (auto v : lens) max_n = std::max(max_n, v);
+        std::vector<unsigned long long> lens(static_cast<size_t>(world));
+        for (int r = 0; r < world; ++r) { lens[r] = lens2[2 * r]; max_n = std::max(max_n, lens[r]); }
+        // the tables padded to the longest, one all-gather (xGMI is a full mesh: every GPU pushes its table on all links at once)
         const size_t row = static_cast<size_t>(max_n) * sizeof(cm_partial_entry);
-        if (row > send_cap) { if (send) HIPCHECK(hipFree(send)); HIPCHECK(hipMalloc(&send, row)); send_cap = row; }
-        if (row * world > gathered_cap) { if (gathered) HIPCHECK(hipFree(gathered)); HIPCHECK(hipMalloc(&gathered, row * world)); gathered_cap = row * world; }
-        if (n_mine) HIPCHECK(hipMemcpyAsync(send, d_table, static_cast<size_t>(n_mine) * sizeof(cm_partial_entry), hipMemcpyDeviceToDevice, stream));
-        NCCLCHECK(ncclAllGather(send, gathered, row, ncclUint8, comm, stream));
-        HIPCHECK(hipStreamSynchronize(stream));
+        if (row * world > gathered_cap) { if (gathered) STEP_HIP(hipFree(gathered)); STEP_HIP(hipMalloc(&gathered, row * world)); gathered_cap = row * world; }
+        const void* src = d_table;
+        if (!d_table || max_n > own_cap) {                      // (no table here, or a peer's is longer than this rank's buffer: stage)
+            if (row > send_cap) { if (send) STEP_HIP(hipFree(send)); STEP_HIP(hipMalloc(&send, row)); send_cap = row; }
+            if (n_mine) STEP_HIP(hipMemcpyAsync(send, d_table, static_cast<size_t>(n_mine) * sizeof(cm_partial_entry), hipMemcpyDeviceToDevice, stream));
+            src = send;
+        }
+        STEP_HIP(hipEventRecord(ev_x0, stream));
+        STEP_NCCL(ncclAllGather(src, gathered, row, ncclUint8, comm, stream));
+        STEP_HIP(hipEventRecord(ev_x1, stream));                 // (no host wait: cm_merge_tables runs behind the all-gather on the same stream)
         const auto t2 = std::chrono::steady_clock::now();
         std::vector<const void*> tables(static_cast<size_t>(world));
         std::vector<uint64_t> counts(static_cast<size_t>(world));
         for (int r = 0; r < world; ++r) { tables[r] = static_cast<const char*>(gathered) + row * r; counts[r] = lens[r]; }
-        CMCHECK(cm_merge_tables(ctx, tables.data(), counts.data(), static_cast<uint32_t>(world), &p, &res));
+        if (cm_merge_tables(ctx, tables.data(), counts.data(), static_cast<uint32_t>(world), &p, &res) < 0) {
+            my_err = 3;
+            std::fprintf(stderr, "rank %d: %s\n", rank, cm_last_error(ctx));
+        }
         const auto t3 = std::chrono::steady_clock::now();
         if (it) {   // (the first frame allocates)
+            float x_ms = 0.f;                                    // the table all-gather on the device (the length exchange is in t2 - t1)
+            (void)hipEventElapsedTime(&x_ms, ev_x0, ev_x1);
             t_partial += std::chrono::duration<double>(t1 - t0).count();
-            t_exchange += std::chrono::duration<double>(t2 - t1).count();
-            t_merge += std::chrono::duration<double>(t3 - t2).count();
+            t_exchange += std::chrono::duration<double>(t2 - t1).count() + 1e-3 * x_ms;
+            t_merge += std::max(0.0, std::chrono::duration<double>(t3 - t2).count() - 1e-3 * x_ms);
         }
+    }
+    if (failed_rank >= 0) {
+        std::fprintf(stderr, "rank %d: rank %d reported a failure; every rank leaves\n", rank, failed_rank);
+        cm_destroy(ctx);
+        (void)ncclCommDestroy(comm);
+        if (rank == 0) std::remove(rendezvous.c_str());
+        return 1;
     }
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_all0).count();
     double checksum = 0;
@@ -192,5 +245,6 @@ int main(int argc, char** argv) {
     cm_destroy(ctx);
     for (void* d : dev_clouds) if (d) (void)hipFree(d);
     (void)ncclCommDestroy(comm);
+    if (rank == 0) std::remove(rendezvous.c_str());
     return res.status < 0 ? 1 : 0;
 }

@@ -296,6 +296,32 @@ def test_cfg5_runner_two_processes_gloo_on_one_gpu():
     assert out["config"]["gathered_entries"] >= out["config"]["voxels_out"] > 0
 
 
+@pytest.mark.gpu
+def test_frame_sharded_bench_two_processes_gloo_on_one_gpu():
+    """the N > 1 launch of the headline bench as the driver does it — `python -m torch.distributed.run
+    --nproc-per-node 2 bench.py --gpus 2 ...` — rehearsed on one GPU (--single-device --backend gloo, reduced clouds): every
+    rank runs its own frame stream (frames are independent units: no data-path collective), barrier + max-over-ranks
+    timing, rank 0 prints the contract line. Checks that the N > 1 path starts, finishes and reports whole-job figures."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("CM_PATH", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+           "--single-device", "--points-per-sensor", "100000", "--steps", "12", "--warmup", "3", "--stream-frames", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 12 and out["scaling"] == "weak"
+    assert out["config"]["points_per_frame"] == 400_000 and out["config"]["voxels_out"] > 0
+    # whole-job value: both ranks' frames over the slower rank's time
+    assert abs(out["value"] - 2 * 12 * 400_000 / (out["ms_per_step"] * 1e-3 * 12)) <= 1e-6 * out["value"]
+    assert "REHEARSAL" in out["config"]["workload"]
+
+
 def _splitmix_clouds(n_sensors, n_points, seed=5001):
     """The generator of cloud_merger_amd/host/fused_main.cpp, vectorised: sensor s draws 4 values per point from
     splitmix64(seed + s) — x, y, z uniform in the cfg5 crop box widened by 10 %, intensity in [0, 255)."""
