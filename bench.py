@@ -52,7 +52,8 @@ def parse():
     ap.add_argument("--static", action="store_true", help="the round-1 loop: one frame resubmitted every step")
     ap.add_argument("--source-hash", action="store_true", help="print the hash of the kernel sources and exit (scripts/pmc_traffic.sh)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffer (PCIe-inclusive) runs")
-    ap.add_argument("--dense", action="store_true", help="config 3: points drawn inside the ROI (the sort-stress variant)")
+    ap.add_argument("--dense", action="store_true", help="config 3: points drawn inside the ROI (the sort-stress variant); config 5: "
+                    "points drawn inside the crop box on shared structure (the ranks' tables hold the same voxels: real merges)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
                     help="2: headline (BASELINE.json configs[1]); 3: configs[2]; 5: configs[4], the single fused cloud — the "
                          "16 sensors dealt to the ranks, partial tables all-gathered (RCCL), merged on every rank")
@@ -104,12 +105,15 @@ def main_fused(args):
     from cloud_merger_amd import capi, fused, synth
     n_sensors = 16
     nps = args.points_per_sensor or 4_000_000
-    sensors, params = synth.config5_shard(rank, world, n_per_sensor=nps, n_sensors=n_sensors, min_pts=args.min_pts)
+    gen5 = synth.config5_dense_shard if args.dense else synth.config5_shard
+    sensors, params = gen5(rank, world, n_per_sensor=nps, n_sensors=n_sensors, min_pts=args.min_pts)
     n_rank = sum(s.n for s in sensors)
     n_total = n_sensors * nps
     dev_clouds = [torch.from_numpy(np.ascontiguousarray(s.data).view(np.uint8).reshape(-1)).to(dev) for s in sensors]
     torch.cuda.synchronize()
-    cm = capi.CloudMerger(max_points_total=max(n_rank, 1 << 16), max_sensors=max(1, len(sensors)), device=local_rank,
+    # (cm_merge_tables sorts ALL ranks' entries: at most one per surviving point of the whole frame — the dense variant's tables
+    # come close to that, the synthesised cfg5's hold a few hundred thousand entries)
+    cm = capi.CloudMerger(max_points_total=max(n_total if args.dense else n_rank, 1 << 16), max_sensors=max(1, len(sensors)), device=local_rank,
                           flags=capi.FLAG_OCCUPANCY if args.check else 0)
     cm.set_stream(torch.cuda.current_stream().cuda_stream)
     for k, s in enumerate(sensors):
@@ -163,7 +167,8 @@ def main_fused(args):
         "value": args.steps * n_total / elapsed, "unit": "points/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"cfg5: {n_sensors} x {nps} XYZI float32 points, yaw-only SE(3), 1 cm voxel, crop x[-15,45] y[-5,5] "
+        "config": {"workload": f"cfg5{' (dense variant: points drawn inside the crop box, 70 % on a road surface shared by all sensors)' if args.dense else ''}: "
+                               f"{n_sensors} x {nps} XYZI float32 points, yaw-only SE(3), 1 cm voxel, crop x[-15,45] y[-5,5] "
                                "z[-0.5,3]; one fused cloud on every rank",
                    "points_per_frame": n_total, "points_per_rank": n_rank, "voxels_out": n_out,
                    "min_points_per_voxel": args.min_pts, "sharding": f"sensor s on rank s mod {world}",
@@ -172,6 +177,8 @@ def main_fused(args):
                                  else "none (one rank)",
                    "step_ms_worst_rank": worst,
                    "table_entries_this_rank": int(last.get("table_entries", 0)),
+                   "table_bytes_this_rank": 32 * int(last.get("table_entries", 0)),
+                   "points_kept_this_rank": int(getattr(res, "n_merged", 0)),
                    "gathered_entries": int(last.get("gathered_entries", 0)),
                    "gathered_bytes": 32 * int(last.get("gathered_entries", 0)),
                    "rehearsal_single_device": bool(args.single_device)},
@@ -181,7 +188,7 @@ def main_fused(args):
     }
     if args.check and rank == 0:
         from oracle import oracle
-        allsens = synth.config5_shard(0, 1, n_per_sensor=nps, n_sensors=n_sensors, min_pts=args.min_pts)[0]   # all 16, in sensor order
+        allsens = gen5(0, 1, n_per_sensor=nps, n_sensors=n_sensors, min_pts=args.min_pts)[0]   # all 16, in sensor order
         st, _, ref, rep = oracle.merge_voxelize(allsens, params, threads=6, stable=True, want_merged=False)
         cells, counts = cm.cells(n_out)
         got = cm.result(n_out)

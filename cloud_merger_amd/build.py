@@ -18,13 +18,16 @@ LIB_PATH = os.path.join(LIB_DIR, "libcloudmerge_hip.so")
 # shipped library holds no such code.
 HOOKS_LIB_PATH = os.path.join(LIB_DIR, "libcloudmerge_hip_testhooks.so")
 SOURCES = ["cm_kernels.hip", "cm_kernels_v2.hip", "cm_kernels_v3.hip", "cm_kernels_v4.hip", "cm_kernels_ground.hip", "cm_api.cpp"]
-HEADERS = ["cm_device.h", "cm_kernels.h", "cm_common.hpp", os.path.join("..", "..", "include", "cloudmerge.h")]
+HEADERS = ["cm_device.h", "cm_kernels.h", "cm_common.hpp", "cloudmerge.map", os.path.join("..", "..", "include", "cloudmerge.h")]
 
 # -ffp-contract=off / -fno-fast-math: occupancy must match the reference bit for bit, so no FMA
 # contraction on the device or in the host-side quaternion/grid arithmetic (SURVEY.md §7 hard part 1).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical", "-fvisibility=hidden",
          "-Wl,-rpath,/opt/rocm/lib"]
+# Only the C-ABI leaves the library: a linker version script keeps the weak libstdc++ template instantiations (std::string,
+# std::vector helpers) local, which -fvisibility=hidden does not reach.
+VERSION_SCRIPT = os.path.join(CSRC, "cloudmerge.map")
 
 
 def hipcc():
@@ -48,7 +51,7 @@ def build(force=False, save_temps=False, verbose=False, test_hooks=False):
     if not force and not needs_build(out):
         return out
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc()] + FLAGS + ["-I", CSRC, "-o", out]
+    cmd = [hipcc()] + FLAGS + ["-Wl,--version-script=" + VERSION_SCRIPT, "-I", CSRC, "-o", out]
     if test_hooks:
         cmd += ["-DCM_TEST_HOOKS"]
     if os.environ.get("CM_PHASE_TIMING") == "1":       # experiment build: scripts/phase_times.py (never the shipped one)

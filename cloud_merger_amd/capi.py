@@ -34,6 +34,7 @@ SYMBOLS = [
     "cm_local_bounds", "cm_merge_partial", "cm_partial_device", "cm_partial_copy", "cm_merge_tables",
     "cm_set_ground_removal", "cm_ground_copy", "cm_ground_planes",
     "cm_submit_cloud_async", "cm_result_copy_async", "cm_sync", "cm_get_frame_stats",
+    "cm_result_publish_async", "cm_publish_wait", "cm_host_register", "cm_host_unregister",
 ]
 MAX_ZONES = 8
 
@@ -141,6 +142,10 @@ def load():
     L.cm_get_sensor_matrix.argtypes = [vp, u32, C.POINTER(C.c_float)]
     L.cm_submit_cloud.argtypes = [vp, u32, vp, u32, u32, u32, u32, u32, u32]
     L.cm_submit_cloud_device.argtypes = [vp, u32, vp, u32, u32, u32, u32, u32, u32]
+    L.cm_result_publish_async.argtypes = [vp, vp, u64, u32]
+    L.cm_publish_wait.argtypes = [vp]
+    L.cm_host_register.argtypes = [vp, C.c_size_t]
+    L.cm_host_unregister.argtypes = [vp]
     L.cm_submit_cloud_async.argtypes = [vp, u32, vp, u32, u32, u32, u32, u32, u32]
     L.cm_result_copy_async.argtypes = [vp, vp, u64]
     L.cm_sync.argtypes = [vp]
@@ -294,6 +299,14 @@ class CloudMerger:
 
     def sync(self):
         self._check(self._lib.cm_sync(self._ctx), "cm_sync")
+
+    def publish_async(self, host_ptr, capacity, step_out=16):
+        """Copy-out of the last waited-for frame on the context's publish stream (cm_result_publish_async)."""
+        self._check(self._lib.cm_result_publish_async(self._ctx, C.c_void_p(host_ptr), int(capacity), int(step_out)),
+                    "cm_result_publish_async")
+
+    def publish_wait(self):
+        self._check(self._lib.cm_publish_wait(self._ctx), "cm_publish_wait")
 
     def frame_stats(self):
         fs = FrameStats()

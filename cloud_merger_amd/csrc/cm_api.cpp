@@ -162,6 +162,14 @@ struct cm_ctx {
     int cell_min_b[3] = {0, 0, 0}, cell_div_b[3] = {1, 1, 1};   // grid the cells in out_key are relative to
     uint64_t n_redone = 0;               // frames the bucket path handed back to the classic one
 
+    // pipelined publish (cm_result_publish_async): the result buffers exist twice, so that the copy-out of frame n runs on
+    // its own stream beside the kernels of frame n + 1
+    void* out_other = nullptr;           // the result buffer the frame in flight does NOT write
+    void* out32_other = nullptr;
+    hipStream_t pub_stream = nullptr;
+    hipEvent_t ev_pub[2] = {nullptr, nullptr};   // [0]: the last copy-out that read `out`, [1]: ... `out_other`
+    bool pub_pending[2] = {false, false};
+
     // quantile passes (cm_kernels_v4.hip): one global pass into buckets cut at the last frame's quantiles
     int quant_mode = 0;                  // CM_QUANT: 0 auto, 1 never
     uint32_t* spl[2] = {nullptr, nullptr};   // splitters: a frame reads spl[spl_cur]; its finish writes spl[spl_cur ^ 1]
@@ -284,6 +292,9 @@ void free_all(cm_ctx* c) {
     F(c->seg_counts); F(c->seg_tile_counts); F(c->seg_groups); F(c->grp); F(c->partials); F(c->out_key); F(c->out_cnt); F(c->merged_total); F(c->out); F(c->merged); F(c->partial); F(c->table_entries); F(c->mask); F(c->sorted_pts); F(c->rows); F(c->d_state_o);
     F(c->stage32); F(c->out32); F(c->rec_a); F(c->rec_b); F(c->dig); F(c->tile_state); F(c->wave_cnt); F(c->records);
     F(c->spl[0]); F(c->spl[1]); F(c->qcnt); F(c->qtot); F(c->qbofs); F(c->qbid);
+    F(c->out_other); F(c->out32_other);
+    if (c->pub_stream) (void)hipStreamDestroy(c->pub_stream);
+    for (auto e : c->ev_pub) if (e) (void)hipEventDestroy(e);
     F(c->d_ground); F(c->d_state_g); F(c->gmask); F(c->zone_off); F(c->d_planes); F(c->hyp0); F(c->valid0); F(c->counts0); F(c->chunk_sums); F(c->bmask); F(c->zcode);
     F(c->d_frame); F(c->d_tiles); F(c->d_state[0]); F(c->d_state[1]);
     if (c->h_state) (void)hipHostFree(c->h_state);
@@ -672,9 +683,9 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
         uint32_t* grp_cnt = reinterpret_cast<uint32_t*>(c->tile_state + f.n_padded / 2048);
         uint32_t* skey = c->out_key ? c->keys_a : nullptr;
         prof_mark(c, "k3_local");
-        // (the finish also leaves the quantiles of its sorted records: the next frame's splitters, cm_kernels_v4.hip — not
-        // with L = 0, where a tile's sorted range may reach beyond what it holds in LDS)
-        uint32_t* spl_next = (mode == 0 && low_bits != 0) ? c->spl[c->spl_cur ^ 1] : nullptr;
+        // (the finish also leaves the quantiles of its sorted records: the next frame's splitters, cm_kernels_v4.hip; with
+        // L = 0 a tile's sorted range may reach beyond what it holds in LDS — the frame then says so: CmFrameState.spl_incomplete)
+        uint32_t* spl_next = mode == 0 ? c->spl[c->spl_cur ^ 1] : nullptr;
         c->wrote_spl = spl_next != nullptr;
         cmk3_local(st, c->d_frame, state, c->h_state_dev, rec_sorted, c->tile_state, grp_cnt, stage, skey, c->vals_a, mode == 1,
                    low_bits, nt_later * CM_TILE, nullptr, nullptr, 0u, spl_next);
@@ -749,6 +760,18 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
     c->prof_used = 0;
     c->last_mode = mode;
     c->bytes_d2h = 0;
+    if (c->pub_pending[0]) {
+        // A copy-out (cm_result_publish_async) may still be reading the last frame's result: this frame writes the other
+        // pair of buffers, and waits ON THE DEVICE for whatever copy-out read those (two frames ago: long done).
+        std::swap(c->out, c->out_other);
+        std::swap(c->out32, c->out32_other);
+        std::swap(c->ev_pub[0], c->ev_pub[1]);
+        std::swap(c->pub_pending[0], c->pub_pending[1]);
+        if (c->pub_pending[0]) {
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_pub[0], 0));
+            c->pub_pending[0] = false;
+        }
+    }
 
     if (f.n_padded == 0) {                             // every submitted cloud is empty
         c->frame_had_ground = c->ground_on && mode == 0;   // ... so are the ground cloud and every slab (no stale planes)
@@ -821,7 +844,7 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
                 const uint32_t low = kb > 8 * g ? kb - 8 * g : 0;
                 // Quantile passes (one global pass instead of g): the last frame of this context left the quantiles of its
                 // sorted records, as indices of this very grid, and this frame is about as large.
-                bool quant = mode == 0 && !pre && c->quant_mode != 1 && c->finish_mode != 2 && spl_ok && g >= 2 && low != 0 &&
+                bool quant = mode == 0 && !pre && c->quant_mode != 1 && c->finish_mode != 2 && spl_ok && g >= 2 &&
                              kb < 32 && f.n_tiles <= CM4_MAX_TILES && !(gm == 1 && pack_survivors(c)) &&
                              std::memcmp(c->spl_min_b, f.box_min_b, sizeof c->spl_min_b) == 0 &&
                              std::memcmp(c->spl_div_b, f.box_div_b, sizeof c->spl_div_b) == 0 &&
@@ -1213,7 +1236,7 @@ int wait_frame(cm_ctx* c, cm_result* res) {
             update_predicted_box(c, h.min_p, h.max_p, leaf);
         }
         if (h.status == CM_OK) c->last_n_merged = h.n_valid;
-        if (h.status == CM_OK && c->last_v2 && c->wrote_spl && h.n_valid) {
+        if (h.status == CM_OK && c->last_v2 && c->wrote_spl && h.n_valid && !h.spl_incomplete) {
             // the finish left the quantiles of this frame's sorted records: the next frame's splitters (cm_kernels_v4.hip)
             c->spl_cur ^= 1;
             c->spl_valid = true;
@@ -1502,10 +1525,53 @@ int cm_result_copy_async(cm_ctx* c, void* host_dst, uint64_t capacity_points) {
     return CM_OK;
 }
 
+int cm_result_publish_async(cm_ctx* c, void* host_dst, uint64_t capacity_points, uint32_t step_out) {
+    if (!c) return CM_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->merge_mu);
+    if (!c->have_result) return fail(c, CM_BAD_ARG, "no result");
+    if (c->pending) return fail(c, CM_BAD_ARG, "a frame is in flight: publish its predecessor before enqueueing it");
+    if (step_out == 0) step_out = 16;
+    if (step_out != 16 && step_out != 32) return fail(c, CM_BAD_ARG, "point_step_out must be 16 or 32");
+    const uint64_t n = c->result.n_out;
+    if (n > capacity_points) return fail(c, CM_CAPACITY, "destination too small");
+    if (n == 0) return CM_OK;
+    if (!host_dst) return CM_BAD_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->pub_stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->pub_stream, hipStreamNonBlocking));
+        for (auto& e : c->ev_pub) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_TRY(c, hipMalloc(&c->out_other, static_cast<size_t>(c->cap_padded) * 16));
+    }
+    // (the frame has been waited for — cm_wait returned its counts — so its result is complete; an overflow fallback's
+    // merged cloud was written on c->stream and synchronised as well)
+    if (step_out == 16) {
+        HIP_TRY(c, hipMemcpyAsync(host_dst, c->out, n * 16, hipMemcpyDeviceToHost, c->pub_stream));
+    } else {
+        if (!c->out32) HIP_TRY(c, hipMalloc(&c->out32, static_cast<size_t>(c->cap_padded) * 32));
+        if (!c->out32_other) HIP_TRY(c, hipMalloc(&c->out32_other, static_cast<size_t>(c->cap_padded) * 32));
+        cmk_to_pcl32(c->pub_stream, c->out, c->out32, static_cast<uint32_t>(n));
+        HIP_TRY(c, hipMemcpyAsync(host_dst, c->out32, n * 32, hipMemcpyDeviceToHost, c->pub_stream));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev_pub[0], c->pub_stream));
+    c->pub_pending[0] = true;
+    c->bytes_d2h += n * step_out;
+    return CM_OK;
+}
+
+int cm_publish_wait(cm_ctx* c) {
+    if (!c) return CM_BAD_ARG;
+    if (!c->pub_stream) return CM_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->pub_stream));
+    // (pub_pending stays as it is: it steers which buffers the next frame writes, and a finished event costs nothing to wait for)
+    return CM_OK;
+}
+
 int cm_sync(cm_ctx* c) {
     if (!c) return CM_BAD_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->pub_stream) HIP_TRY(c, hipStreamSynchronize(c->pub_stream));
     return CM_OK;
 }
 
@@ -1864,6 +1930,14 @@ int cm_host_alloc(void** ptr, size_t bytes) {
     return hipHostMalloc(ptr, bytes, hipHostMallocDefault) == hipSuccess ? CM_OK : CM_HIP_ERROR;
 }
 
+int cm_host_register(void* ptr, size_t bytes) {
+    if (!ptr || !bytes) return CM_BAD_ARG;
+    return hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess ? CM_OK : CM_INTERNAL;
+}
+int cm_host_unregister(void* ptr) {
+    if (!ptr) return CM_BAD_ARG;
+    return hipHostUnregister(ptr) == hipSuccess ? CM_OK : CM_INTERNAL;
+}
 int cm_host_free(void* ptr) {
     return hipHostFree(ptr) == hipSuccess ? CM_OK : CM_HIP_ERROR;
 }

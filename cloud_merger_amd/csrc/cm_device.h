@@ -134,7 +134,8 @@ struct CmGroundPlaneDev {                 // == cm_ground_plane
 struct CmFrameState {
     uint32_t outside;         // bucket path: a point fell outside the predicted box (frame must be redone)
     uint32_t quant_abort;     // quantile passes (cm_kernels_v4.hip): a bucket beyond the finish's capacity — every later kernel leaves
-    uint32_t _unused[4];
+    uint32_t spl_incomplete;  // the finish could not leave every quantile (a voxel reached beyond what a tile holds in LDS): no splitters
+    uint32_t _unused[3];
     uint32_t n_valid_k0;      // valid points counted by the min/max pass
     int32_t status;           // cm_status of the frame (0 OK, 1 EMPTY, 2 OVERFLOW)
     int32_t min_b[3], max_b[3], div_b[3];

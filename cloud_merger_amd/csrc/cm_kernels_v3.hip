@@ -331,6 +331,9 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
     // frame in index order; quantile j of bn sits at record floor(j * n / bn). Each is written by the one tile whose range
     // holds it; tile 0 also writes the fixed ends (splitter 0 = index 0, 0xFFFFFFFF beyond the last bucket).
     if (!PARTIAL && spl_next) {
+        // (a tile whose last voxel runs on beyond its LDS — L = 0 frames only — cannot say which index sits at the positions
+        // out there: the frame then leaves no splitters)
+        if (tail_open && threadIdx.x == 0) st->spl_incomplete = 1u;
         const uint32_t bn = cm_quant_buckets(n);
         if (bn && m) {
             const unsigned long long g0 = static_cast<unsigned long long>(base) + a, g1 = g0 + m;

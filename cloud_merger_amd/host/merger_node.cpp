@@ -182,7 +182,65 @@ CloudMergerNode::CloudMergerNode(const NodeConfig& cfg)
 }
 
 CloudMergerNode::~CloudMergerNode() {
+    if (ctx_) (void)cm_sync(ctx_);
+    for (void* p : pipe_registered_) if (p) (void)cm_host_unregister(p);
     if (ctx_) cm_destroy(ctx_);
+}
+
+void CloudMergerNode::flush() {
+    if (!pipe_in_flight_ || !ctx_) return;
+    (void)cm_publish_wait(ctx_);
+    pipe_in_flight_ = false;
+    if (publish_) publish_(cfg_.voxel_topic, pipe_msg_[pipe_cur_ ^ 1]);
+    frames_.fetch_add(1);
+}
+
+// spin_once with NodeConfig::pipelined_publish: enqueue frame n; while it computes, finish and publish frame n - 1; wait
+// for frame n; start its copy-out (cm_result_publish_async: a stream of its own, double-buffered result) and return.
+int CloudMergerNode::spin_once_pipelined(cm_result* res) {
+    const int eq = cm_merge_voxelize_async(ctx_, &cfg_.params);        // fusePointclouds + voxelgrid, enqueued
+    flush();                                                            // frame n - 1 goes out while frame n runs
+    if (res) *res = cm_result{};
+    if (eq == CM_NOT_READY) return eq;                                  // :575 — nothing fused this tick
+    if (eq < 0) { set_error(cm_last_error(ctx_)); return eq; }
+    cm_result r{};
+    const int st = cm_wait(ctx_, &r);
+    if (res) *res = r;
+    if (st < 0) { set_error(cm_last_error(ctx_)); return st; }
+    {
+        cm_frame_stats fs;
+        if (cm_get_frame_stats(ctx_, &fs) == CM_OK)
+            for (uint32_t k = 0; k < fs.n_sensors; ++k)
+                if (fs.sensor[k] < consumed_.size()) consumed_[fs.sensor[k]].store(fs.generation[k]);
+    }
+    PointCloud2& msg = pipe_msg_[pipe_cur_];
+    const bool pcl = cfg_.publish_pcl_layout;
+    if (msg.fields.empty() || msg.point_step != (pcl ? 32u : 16u)) msg = pcl ? make_pcl_xyzi_message(0) : make_xyzi16_message(0);
+    // The payload buffer is reserved once at the largest cloud the context can produce and made DMA-able: the copy-out
+    // then is a true asynchronous transfer straight into the message that goes on the wire.
+    const size_t cap_bytes = static_cast<size_t>(cfg_.max_points_total) * msg.point_step;
+    if (msg.data.capacity() < cap_bytes || pipe_registered_[pipe_cur_] != msg.data.data()) {
+        if (pipe_registered_[pipe_cur_]) { (void)cm_host_unregister(pipe_registered_[pipe_cur_]); pipe_registered_[pipe_cur_] = nullptr; }
+        msg.data.reserve(cap_bytes);
+        msg.data.resize(1);                                             // (data() of an empty vector need not be its buffer)
+        if (cm_host_register(msg.data.data(), cap_bytes) == CM_OK) pipe_registered_[pipe_cur_] = msg.data.data();
+    }
+    msg.height = 1; msg.width = static_cast<uint32_t>(r.n_out);
+    msg.row_step = msg.point_step * msg.width;
+    msg.data.resize(static_cast<size_t>(r.n_out) * msg.point_step);    // (within the reserved capacity: the buffer stays put)
+    if (st == CM_EMPTY_INPUT) { msg.width = 0; msg.height = 0; msg.row_step = 0; }   // A.4 step 1
+    if (r.n_out) {
+        const int cs = cm_result_publish_async(ctx_, msg.data.data(), r.n_out, msg.point_step);
+        if (cs != CM_OK) { set_error(cm_last_error(ctx_)); return cs; }
+    }
+    msg.header.seq = seq_++;
+    uint64_t newest = 0;
+    for (const auto& t : stamp_ns_) newest = std::max(newest, t.load());
+    msg.header.stamp_ns = (cfg_.stamp_from_inputs && newest) ? newest : clock_();
+    msg.header.frame_id = cfg_.base_frame;
+    pipe_in_flight_ = true;
+    pipe_cur_ ^= 1;
+    return st;
 }
 
 int CloudMergerNode::sensor_by_topic(const std::string& topic) const {
@@ -240,6 +298,7 @@ int CloudMergerNode::spin_once(cm_result* res) {
             return CM_NOT_READY;
         }
     }
+    if (cfg_.pipelined_publish && !cfg_.ground_enable) return spin_once_pipelined(res);
     cm_result r{};
     const int st = cm_merge_voxelize(ctx_, &cfg_.params, &r);      // fusePointclouds + voxelgrid
     if (res) *res = r;

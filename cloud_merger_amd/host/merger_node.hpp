@@ -35,6 +35,11 @@ struct NodeConfig {
     int device = 0;
     uint32_t flags = 0;
     bool publish_pcl_layout = true;                 // 32-byte pcl::PointXYZI records like pcl::toROSMsg
+    // Pipelined publish: spin_once() enqueues frame n, publishes frame n - 1 (whose copy-out has been running on a stream of
+    // its own, into a DMA-able message buffer) while frame n computes, then starts frame n's copy-out and returns — the
+    // voxel cloud reaches its subscribers one tick later, the loop no longer waits for PCIe (flush() publishes the last
+    // one). Off by default: the reference publishes within the tick (:574-577). Not with ground_enable (three clouds per tick).
+    bool pipelined_publish = false;
     // Stamp of the published cloud. false: ros::Time::now() at publish like the reference (:217).
     // true: the newest stamp among the fused input clouds — what pcl::PointCloud::operator+= leaves in
     // the fused cloud's header and what §8f rank 4 proposes.
@@ -111,6 +116,8 @@ public:
     int spin_once(cm_result* res = nullptr);
     // while(ros::ok()) { spin_once(); loop_rate.sleep(); } (:549-584)
     void run(const std::atomic<bool>& stop);
+    // pipelined_publish: publishes the frame whose copy-out is still in flight (end of a replay, shutdown)
+    void flush();
 
     uint64_t frames_published() const { return frames_; }
     uint64_t clouds_dropped_for_sync() const { return dropped_; }
@@ -127,6 +134,11 @@ private:
     std::atomic<uint64_t> frames_{0};
     uint32_t seq_ = 0;
     PointCloud2 out_msg_, side_msg_;               // reused from frame to frame (no 3 MB zero-fill per publish)
+    PointCloud2 pipe_msg_[2];                       // pipelined publish: the message being filled by the copy-out, and the one before
+    void* pipe_registered_[2] = {nullptr, nullptr}; // ... their payload buffers, made DMA-able once (cm_host_register)
+    int pipe_cur_ = 0;
+    bool pipe_in_flight_ = false;
+    int spin_once_pipelined(cm_result* res);
     std::vector<std::atomic<uint64_t>> stamp_ns_;   // stamp of the cloud each sensor slot currently holds
     // A slot holds a cloud no fuse has consumed yet when more submits were accepted for it than the last fuse had seen
     // (cm_frame_stats.generation): exact, whichever way a callback and the fuse interleave.

@@ -18,6 +18,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <deque>
 #include <fstream>
 #include <string>
 #include <thread>
@@ -54,6 +55,7 @@ int main(int argc, char** argv) {
         else if (k == "--rate") rate = std::atof(next());
         else if (k == "--realtime") realtime = true;
         else if (k == "--threads") threads = true;
+        else if (k == "--pipeline") cfg.pipelined_publish = true;   // publish frame n - 1 while frame n computes (merger_node.hpp)
         else if (k == "--repeat") repeat = std::max(1, std::atoi(next()));      // --threads: play the sequence this many times (the first pass is the warm-up: not timed)
         else if (k == "--leaf") { const float v = std::strtof(next(), nullptr); cfg.params.leaf[0] = cfg.params.leaf[1] = cfg.params.leaf[2] = v; }
         else if (k == "--min-pts") cfg.params.min_points_per_voxel = static_cast<uint32_t>(std::atoi(next()));
@@ -105,11 +107,16 @@ int main(int argc, char** argv) {
     }
     uint64_t voxels = 0, points = 0;
     int cur_frame = 0;
+    // frames handed to spin_once whose voxel cloud has not been published yet, oldest first (with --pipeline a frame is
+    // published during the NEXT spin_once, or by flush())
+    std::deque<int> unpublished;
     node.set_publisher([&](const std::string&, const PointCloud2& msg) {
         voxels += msg.num_points();
+        const int pub_frame = unpublished.empty() ? cur_frame : unpublished.front();
+        if (!unpublished.empty()) unpublished.pop_front();
         if (!out_dir.empty()) {
             char buf[64];
-            std::snprintf(buf, sizeof buf, "/voxel_%04d.pcd", cur_frame);
+            std::snprintf(buf, sizeof buf, "/voxel_%04d.pcd", pub_frame);
             std::string e;
             if (!write_pcd(out_dir + buf, msg, &e)) std::fprintf(stderr, "%s\n", e.c_str());
         }
@@ -148,22 +155,25 @@ int main(int argc, char** argv) {
             if (static_cast<size_t>(done) == n_warm && n_warm) { t0 = std::chrono::steady_clock::now(); voxels_warm = voxels; }
             cur_frame = my_frames[static_cast<size_t>(done) % all.size()];
             cm_result r{};
+            unpublished.push_back(cur_frame);
             const int st = node.spin_once(&r);
-            if (st == CM_NOT_READY) { std::this_thread::yield(); continue; }
+            if (st == CM_NOT_READY) { unpublished.pop_back(); std::this_thread::yield(); continue; }
             if (st < 0) { std::fprintf(stderr, "frame %d: %s\n", cur_frame, cm_status_string(st)); failed.store(true); break; }
             ++done;
             if (realtime) std::this_thread::sleep_until(t0 + std::chrono::duration<double>(done / rate));
         }
         for (auto& t : subs) t.join();
         if (failed.load()) return 1;
+        node.flush();
         const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         const int timed = done - static_cast<int>(n_warm);
         const uint64_t pts_timed = points * static_cast<uint64_t>(repeat > 1 ? repeat - 1 : 1);
         std::printf("{\"rank\": %d, \"world\": %d, \"frames\": %d, \"points_in\": %llu, \"voxels_out\": %llu, "
                     "\"wall_s\": %.6f, \"submit_merge_publish_s\": %.6f, \"frames_per_s\": %.2f, \"points_per_s\": %.3e, "
-                    "\"mode\": \"subscriber threads (%d) + loop thread\", \"warmup_frames\": %d}\n",
+                    "\"mode\": \"subscriber threads (%d) + loop thread%s\", \"warmup_frames\": %d}\n",
                     rank, world, timed, static_cast<unsigned long long>(pts_timed), static_cast<unsigned long long>(voxels - voxels_warm),
-                    wall, wall, timed / wall, pts_timed / wall, n_sensors, static_cast<int>(n_warm));
+                    wall, wall, timed / wall, pts_timed / wall, n_sensors, cfg.pipelined_publish ? ", pipelined publish" : "",
+                    static_cast<int>(n_warm));
         return 0;
     }
 
@@ -183,12 +193,14 @@ int main(int argc, char** argv) {
             if (st != CM_OK) { std::fprintf(stderr, "on_cloud: %s (%s)\n", cm_status_string(st), node.error().c_str()); return 1; }
         }
         cm_result r{};
+        unpublished.push_back(f);
         const int st = node.spin_once(&r);
         t_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - g0).count();
         if (st < 0 || st == CM_NOT_READY) { std::fprintf(stderr, "frame %d: %s\n", f, cm_status_string(st)); return 1; }
         ++done;
         if (realtime) std::this_thread::sleep_until(t0 + std::chrono::duration<double>(done / rate));
     }
+    node.flush();
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::printf("{\"rank\": %d, \"world\": %d, \"frames\": %d, \"points_in\": %llu, \"voxels_out\": %llu, "
                 "\"wall_s\": %.6f, \"submit_merge_publish_s\": %.6f, \"frames_per_s\": %.2f, \"points_per_s\": %.3e}\n",

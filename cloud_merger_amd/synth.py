@@ -169,6 +169,40 @@ def config5_shard(rank, world, n_per_sensor=4_000_000, n_sensors=16, min_pts=0, 
                                 crop_min=(-15.0, -5.0, -0.5), crop_max=(45.0, 5.0, 3.0))
 
 
+CFG5_BOX_MIN, CFG5_BOX_MAX = (-15.0, -5.0, -0.5), (45.0, 5.0, 3.0)
+
+
+def config5_dense_shard(rank, world, n_per_sensor=4_000_000, n_sensors=16, min_pts=0, leaf=0.01):
+    """cfg5's sensors, box and leaf with the points drawn INSIDE the crop box (about 85 % survive instead of 1 %), on
+    shared structure: 70 % on a road surface (z = 0, sigma 1 cm: a layer two or three 1 cm cells thick), 30 % clutter.
+    Every sensor sees the whole corridor, so the ranks' partial tables hold the SAME voxels over and over — the fuse has
+    real merges to do, and a voxel's min_points_per_voxel is only met across ranks (what the synthesised cfg5 never had:
+    132 voxels out of 64 M points, VERDICT r2 missing 3). This rank's share of the sensors."""
+    mine = [s for s in range(n_sensors) if s % world == rank]
+    lo, hi = np.asarray(CFG5_BOX_MIN, np.float64), np.asarray(CFG5_BOX_MAX, np.float64)
+    ext = hi - lo
+    sensors = []
+    for s in mine:
+        rng = _rng(5501 + s)
+        yaw = rng.uniform(-np.pi, np.pi)
+        q = yaw_quaternion(yaw)
+        t = rng.uniform(-2, 2, 3)
+        ng = int(round(0.7 * n_per_sensor))
+        w = np.empty((n_per_sensor, 3))
+        w[:, 0] = rng.uniform(lo[0] - 0.04 * ext[0], hi[0] + 0.04 * ext[0], n_per_sensor)
+        w[:, 1] = rng.uniform(lo[1] - 0.04 * ext[1], hi[1] + 0.04 * ext[1], n_per_sensor)
+        w[:ng, 2] = rng.normal(0.0, 0.01, ng)
+        w[ng:, 2] = rng.uniform(lo[2], hi[2], n_per_sensor - ng)
+        c, sn = np.cos(yaw), np.sin(yaw)
+        d = w - t                                                  # into the sensor frame: p_sensor = R^T (p_world - t)
+        xyz = np.stack([c * d[:, 0] + sn * d[:, 1], -sn * d[:, 0] + c * d[:, 1], d[:, 2]], axis=1).astype(np.float32)
+        inten = rng.uniform(0.0, 255.0, n_per_sensor).astype(np.float32)
+        perm = rng.permutation(n_per_sensor)
+        data, lay = pack(xyz[perm], inten[perm], "xyzi16")
+        sensors.append(SensorCloud(data=data, n=n_per_sensor, q_xyzw=q, t_xyz=t, **lay))
+    return sensors, MergeParams(leaf=(leaf,) * 3, min_points_per_voxel=min_pts, crop_min=CFG5_BOX_MIN, crop_max=CFG5_BOX_MAX)
+
+
 def velodyne_frame(frame, sensor, rings=32, azimuths=3750):
     """cfg4: one Velodyne-like sweep (rings x azimuths) of a plane + boxes scene, seeded per
     (frame, sensor). Returns xyz, intensity in the sensor frame."""

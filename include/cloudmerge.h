@@ -181,7 +181,15 @@ CM_API int cm_result_copy(cm_ctx* ctx, void* host_dst, uint64_t capacity_points,
  * stream; `host_dst` (cm_host_alloc memory for a true DMA) is complete when cm_sync returns. The next frame
  * may be enqueued right away (stream order keeps it off the result until the copy has read it). */
 CM_API int cm_result_copy_async(cm_ctx* ctx, void* host_dst, uint64_t capacity_points);
-/* Waits for everything enqueued on the context's stream. */
+/* Pipelined publish (the loop body of the reference publishes every tick, pc_preprocessing_main.cpp:199-220, :574-577): the
+ * copy-out of the LAST WAITED-FOR frame — 16-byte records or the 32-byte pcl::PointXYZI images — is enqueued on a stream of
+ * its own, and the next frame may be enqueued right away: its kernels run BESIDE the copy (the result buffers exist twice;
+ * a frame only waits, on the device, for the copy that read the buffers it is about to write, i.e. the one of two frames
+ * ago). `host_dst` — cm_host_alloc memory, or any buffer made DMA-able with cm_host_register — is complete when
+ * cm_publish_wait (or cm_sync) returns. Call between cm_wait and the next cm_merge_voxelize_async. */
+CM_API int cm_result_publish_async(cm_ctx* ctx, void* host_dst, uint64_t capacity_points, uint32_t point_step_out);
+CM_API int cm_publish_wait(cm_ctx* ctx);
+/* Waits for everything enqueued on the context's streams. */
 CM_API int cm_sync(cm_ctx* ctx);
 /* Device pointer of the compact 16-byte result records (valid until the next merge). */
 CM_API int cm_result_device(cm_ctx* ctx, const void** dev_ptr, uint64_t* n_points);
@@ -289,6 +297,9 @@ CM_API int cm_ground_planes(cm_ctx* ctx, cm_ground_plane* planes, uint32_t capac
 /* ---- host memory helpers (pinned staging for PointCloud2 payloads) --------------------------- */
 CM_API int cm_host_alloc(void** ptr, size_t bytes);
 CM_API int cm_host_free(void* ptr);
+/* Makes memory the caller already owns (a message's payload vector) DMA-able for the asynchronous copies, and undoes it. */
+CM_API int cm_host_register(void* ptr, size_t bytes);
+CM_API int cm_host_unregister(void* ptr);
 
 #ifdef __cplusplus
 }

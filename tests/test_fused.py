@@ -297,6 +297,68 @@ def test_cfg5_runner_two_processes_gloo_on_one_gpu():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_cfg5_dense_variant_contexts_as_ranks(world):
+    """`bench.py --config 5 --dense` at reduced size: 16 sensors drawn inside the crop box on a shared
+    road surface, a 10 cm leaf so that the reduced clouds are as dense per voxel as the full ones at 1 cm; the sensors
+    dealt to 2 or 4 ranks (contexts on one GPU): most points survive the crop, most voxels live on several ranks, and
+    min_points_per_voxel = 2 is met across ranks only — cm_merge_partial -> cm_merge_tables against the oracle."""
+    from cloud_merger_amd import capi
+    n_sensors, nps = 16, 40_000
+    per_rank = [synth.config5_dense_shard(r, world, n_per_sensor=nps, n_sensors=n_sensors, min_pts=2, leaf=0.1) for r in range(world)]
+    params = per_rank[0][1]
+    allsens = [None] * n_sensors
+    for r in range(world):
+        for k, s in enumerate(fused.shard_sensors(n_sensors, r, world)):
+            allsens[s] = per_rank[r][0][k]
+    cms, parts, kept = [], [], 0
+    try:
+        for r in range(world):
+            cm = capi.CloudMerger(max_points_total=n_sensors * nps, max_sensors=n_sensors, flags=capi.FLAG_OCCUPANCY)
+            for k, sc in enumerate(per_rank[r][0]):
+                cm.set_transform(k, sc.q_xyzw, sc.t_xyz)
+                cm.submit(k, sc)
+            cms.append(cm)
+            res = cm.merge_partial(params, None)
+            assert res.status == capi.OK
+            kept += res.n_merged
+            parts.append(cm.partial_device())
+        assert kept >= 0.8 * n_sensors * nps, "the dense variant keeps most of its points"
+        res = cms[0].merge_tables([p[0] for p in parts], [p[1] for p in parts], params)
+        out = cms[0].result(res.n_out)
+        cells, counts = cms[0].cells(res.n_out)
+        st, _, ref, rep = oracle.merge_voxelize(allsens, params, threads=4, stable=True)
+        assert res.status == st == capi.OK and res.n_out == rep.n_out > 20_000
+        assert sum(p[1] for p in parts) > 1.3 * res.n_merged, "many voxels live on several ranks"
+        assert np.array_equal(cells, rep.cells) and np.array_equal(counts, rep.counts)
+        got = np.stack([out["x"], out["y"], out["z"], out["intensity"]], axis=1)
+        assert_centroids_close(got, xyzi_of(ref))
+    finally:
+        for cm in cms:
+            cm.close()
+
+
+@pytest.mark.gpu
+def test_cfg5_dense_runner_two_processes_gloo_on_one_gpu():
+    """`bench.py --config 5 --dense` under torch.distributed.run, two ranks on one GPU (gloo rehearsal), --check."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("CM_PATH", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--config", "5", "--dense",
+           "--backend", "gloo", "--single-device", "--points-per-sensor", "100000", "--steps", "3", "--warmup", "1", "--check",
+           "--min-pts", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["parity"]["occupancy_bit_exact"] and out["parity"]["max_abs_dxyz_m"] <= 1e-4
+    assert out["config"]["voxels_out"] > 0 and out["config"]["gathered_entries"] > out["config"]["voxels_out"]
+
+
+@pytest.mark.gpu
 def test_frame_sharded_bench_two_processes_gloo_on_one_gpu():
     """the N > 1 launch of the headline bench as the driver does it — `python -m torch.distributed.run
     --nproc-per-node 2 bench.py --gpus 2 ...` — rehearsed on one GPU (--single-device --backend gloo, reduced clouds): every

@@ -47,8 +47,11 @@ def test_host_unit_tests_gpu(host_bins, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("threads", [False, True])
+@pytest.mark.parametrize("threads", [False, True, "pipeline", "threads+pipeline"])
 def test_replay_sequence_matches_oracle(host_bins, tmp_path, threads):
+    """threads: subscriber threads beside the loop thread; pipeline: NodeConfig::pipelined_publish — frame n - 1 is
+    published (cm_result_publish_async into a registered message buffer) while frame n computes; same clouds either way."""
+    flags = {False: [], True: ["--threads"], "pipeline": ["--pipeline"], "threads+pipeline": ["--threads", "--pipeline"]}[threads]
     from oracle import oracle
     from tests.util import assert_centroids_close, xyzi_of
 
@@ -59,7 +62,7 @@ def test_replay_sequence_matches_oracle(host_bins, tmp_path, threads):
     crop = ["-15", "-5", "-0.5", "60", "5", "3"]
     r = subprocess.run([os.path.join(host_bins, "cloudmerge_replay"), "--dir", seq, "--sensors", str(sensors),
                         "--frames", str(frames), "--leaf", "0.1", "--min-pts", "2", "--crop", *crop, "--out", out]
-                       + (["--threads"] if threads else []),      # subscriber threads beside the loop thread (AsyncSpinner(6), :513)
+                       + flags,      # (--threads: subscriber threads beside the loop thread: AsyncSpinner(6), :513)
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     stats = json.loads(r.stdout.strip().splitlines()[-1])
