@@ -666,8 +666,10 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
                      low_bits + 8 * pass, pass + 1 < n_global ? low_bits + 8 * (pass + 1) : 32u, nt_p, n_groups_p,
                      f.n_padded, c->records, nt, predicted ? 1 : 0, mask, 0, (pack && pass == 0) ? c->rec_b : nullptr, c->wave_cnt,
                      (c->debug_misrank && pass + 1 == n_global) ? 1 : 0, c->d_tile_kept,
-                     // (fewer than a quarter of the points survived the last frame's crop: eight tiles per workgroup)
-                     pack && pass == 0 && !c->debug_misrank && 4ull * c->last_n_merged < c->n_in);
+                     // (fewer than a sixteenth of the points survived the last frame's crop: eight tiles per workgroup)
+                     // (... and few enough that a wave's share of a tile is one load: k2_scatter_sparse takes a chunk of more
+                     // than 64 records through a loop — at 20 % survivors, the live node's ROI, 40 us against 7)
+                     pack && pass == 0 && !c->debug_misrank && 16ull * c->last_n_merged < c->n_in);
     }
     const void* rec_sorted = ((n_global - 1) & 1u) ? c->rec_b : c->rec_a;
     c->last_k3 = c->finish_mode != 2;
@@ -989,13 +991,12 @@ int launch_classic(cm_ctx* c, const cm_params* p, int mode, int grid_mode, uint3
         if (ground_outl) {
             if (!c->bmask) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->bmask), c->cap_padded));
             if (!c->zcode) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->zcode), c->cap_padded));
-            HIP_TRY(c, hipMemsetAsync(c->bmask, 0, f.n_padded, st));
-            HIP_TRY(c, hipMemsetAsync(c->zcode, 0xFF, f.n_padded, st));
         }
         if (!c->ground_uploaded) { cmkg_setup(st, c->ground, c->d_ground); c->ground_uploaded = true; }
-        HIP_TRY(c, hipMemsetAsync(c->d_state_g, 0, sizeof(CmFrameState), st));
-        HIP_TRY(c, hipMemsetAsync(c->mask, 0, f.n_padded, st));
-        HIP_TRY(c, hipMemsetAsync(c->gmask, 0, f.n_padded, st));
+        // (masks and the slab sort's state cleared by ONE launch: they were five hipMemsetAsync calls per tick)
+        prof_mark(c, "kg_clear");
+        cmkg_clear(st, f.n_padded, c->mask, 0, c->gmask, 0, ground_outl ? c->bmask : nullptr, 0, ground_outl ? c->zcode : nullptr, 0xFF,
+                   c->d_state_g, nullptr);
         uint32_t* grp0 = c->grp + gstride * (c->frame_seq & 1u);
         uint32_t* grp0_next = c->grp + gstride * ((c->frame_seq & 1u) ^ 1u);
         ++c->frame_seq;
@@ -1059,7 +1060,19 @@ bool redo_in_measured_box(cm_ctx* c, const CmFrameState& h0) {
     if (!h0.outside || h0.err || !c->last_predicted || c->last_mode != 0 || c->frame_mask || c->last_outl || c->ground_on ||
         c->path_mode == 1 || !c->lds_rank || h0.n_valid_k0 == 0 || c->frame.n_padded == 0)
         return false;
-    CmFrameDev& f = c->frame;
+    // Everything that can still say "no" works on copies: the frame's descriptor and the predicted box only change once the
+    // redo is certain to be launched (a refusal leaves c->frame as the general path's redo expects it — ADVICE r2).
+    CmFrameDev f = c->frame;
+    const bool pred_ok0 = c->pred_ok;
+    float pred_min0[3], pred_max0[3];
+    std::memcpy(pred_min0, c->pred_min, sizeof pred_min0);
+    std::memcpy(pred_max0, c->pred_max, sizeof pred_max0);
+    auto refuse = [&]() {
+        c->pred_ok = pred_ok0;
+        std::memcpy(c->pred_min, pred_min0, sizeof pred_min0);
+        std::memcpy(c->pred_max, pred_max0, sizeof pred_max0);
+        return false;
+    };
     float leaf[3], inv_leaf[3];
     for (int a = 0; a < 3; ++a) {
         if (!std::isfinite(h0.min_p[a]) || !std::isfinite(h0.max_p[a]) || h0.min_p[a] > h0.max_p[a]) return false;
@@ -1068,18 +1081,22 @@ bool redo_in_measured_box(cm_ctx* c, const CmFrameState& h0) {
     }
     set_predicted_box(c, h0.min_p, h0.max_p, leaf);
     uint32_t kb = 0;
-    if (!box_grid(c->pred_min, c->pred_max, inv_leaf, &kb, f.box_min_b, f.box_div_b)) { c->pred_ok = false; return false; }
+    if (!box_grid(c->pred_min, c->pred_max, inv_leaf, &kb, f.box_min_b, f.box_div_b)) { refuse(); c->pred_ok = false; return false; }
     for (int a = 0; a < 3; ++a) {
-        if (f.box_div_b[a] >= (1 << 24)) return false;
+        if (f.box_div_b[a] >= (1 << 24)) return refuse();
         f.ext_min[a] = c->pred_min[a]; f.ext_max[a] = c->pred_max[a];
     }
     f.box_key_bits = kb;
     f.box_predicted = 1u;
     const uint32_t g = bucket_passes(kb, h0.n_valid_k0, c->v2_extra_passes);
-    if (!g) return false;
+    if (!g) return refuse();
+    const CmFrameDev f0 = c->frame;
+    c->frame = f;
     c->h_state->err = 0;
     c->prof_used = 0;
-    return launch_bucket(c, 2, g, kb > 8 * g ? kb - 8 * g : 0, nullptr, nullptr, 0) == CM_OK;
+    if (launch_bucket(c, 2, g, kb > 8 * g ? kb - 8 * g : 0, nullptr, nullptr, 0) == CM_OK) return true;
+    c->frame = f0;
+    return refuse();
 }
 
 int wait_frame(cm_ctx* c, cm_result* res) {

@@ -92,6 +92,9 @@ void cmk4_scatter(hipStream_t s, const CmFrameDev* fd, const CmTileDev* tiles, C
 
 // ---- zone-wise ground removal (cm_kernels_ground.hip) ------------------------------------------
 void cmkg_setup(hipStream_t s, const CmGroundDev& g, CmGroundDev* d_ground);
+// up to four byte arrays of n_bytes (a multiple of 16) set to a value each, up to two state records zeroed: one launch
+void cmkg_clear(hipStream_t s, uint32_t n_bytes, void* p0, unsigned char v0, void* p1, unsigned char v1, void* p2, unsigned char v2,
+                void* p3, unsigned char v3, CmFrameState* st_a, CmFrameState* st_b);
 void cmkg_classify(hipStream_t s, const CmFrameDev* fd, const CmGroundDev* gd, CmFrameState* st, uint32_t* keys,
                    uint32_t* hist, uint32_t* grp_acc, uint32_t* grp_clear_a, uint32_t* grp_clear_b,
                    uint32_t n_group_words, uint32_t n_clear_a_words, unsigned char* keep_mask, unsigned char* zcode,

@@ -81,6 +81,14 @@ __device__ __forceinline__ void buckets_of(const uint32_t* __restrict__ tree, co
     for (int r = 0; r < N; ++r) bk[r] -= CM4_BINS;
 }
 
+// Where counter word `word` (two 16-bit bucket counters) of tile `tile` lives: column blocks of eight words, the tiles of a
+// block one after the other — [word / 8][tile][word % 8]. k4_hist writes and k4_scatter reads 32-byte pieces of it;
+// k4_colscan, whose whole work is this table, reads and writes one contiguous block per workgroup (with rows of 1024 words
+// per tile it fetched every 128-byte line four times, from four workgroups: 15 MB for 4).
+__device__ __forceinline__ size_t cnt_at(uint32_t tile, uint32_t word, uint32_t n_tiles) {
+    return (static_cast<size_t>(word >> 3) * n_tiles + tile) * 8u + (word & 7u);
+}
+
 // The exact bounds of the frame's valid points from the per-tile records (see fold_bounds, cm_kernels_v2.hip).
 __device__ __forceinline__ void fold_bounds4(float* s_f, CmFrameState* __restrict__ st, const float* __restrict__ records,
                                              uint32_t n_records) {
@@ -252,9 +260,10 @@ __global__ __launch_bounds__(CM2_BLOCK) void k4_hist(const CmFrameDev fv, CmFram
         }
     }
     __syncthreads();
+    // The counts go out in column blocks of eight words (cnt_at): k4_colscan then streams one contiguous block per workgroup.
 #pragma unroll
     for (int q = 0; q < CM4_BINS / 2 / CM2_BLOCK; ++q)
-        cnt[static_cast<size_t>(tile) * (CM4_BINS / 2) + q * CM2_BLOCK + threadIdx.x] = lh[q * CM2_BLOCK + threadIdx.x];
+        cnt[cnt_at(tile, q * CM2_BLOCK + threadIdx.x, gridDim.x)] = lh[q * CM2_BLOCK + threadIdx.x];
     if (predicted && threadIdx.x < 8) {                    // record: min xyz, max xyz, count, pad
         const int k = threadIdx.x;
         float v = 0.f;
@@ -293,7 +302,7 @@ __global__ __launch_bounds__(1024) void k4_colscan(CmFrameState* __restrict__ st
 #pragma unroll
     for (int k = 0; k < CM4_SCAN_TPC; ++k) {
         const uint32_t t = c * tpc + k;
-        v[k] = (static_cast<uint32_t>(k) < tpc && t < n_tiles) ? cnt[static_cast<size_t>(t) * (CM4_BINS / 2) + word] : 0u;
+        v[k] = (static_cast<uint32_t>(k) < tpc && t < n_tiles) ? cnt[cnt_at(t, word, n_tiles)] : 0u;
         lo += v[k] & 0xFFFFu; hi += v[k] >> 16;
     }
     // prefix over the chunks: eight of them sit in one wave (lanes 8 apart), the sixteen waves meet in LDS
@@ -316,7 +325,7 @@ __global__ __launch_bounds__(1024) void k4_colscan(CmFrameState* __restrict__ st
 #pragma unroll
     for (int k = 0; k < CM4_SCAN_TPC; ++k) {
         const uint32_t t = c * tpc + k;
-        if (static_cast<uint32_t>(k) < tpc && t < n_tiles) cnt[static_cast<size_t>(t) * (CM4_BINS / 2) + word] = run;
+        if (static_cast<uint32_t>(k) < tpc && t < n_tiles) cnt[cnt_at(t, word, n_tiles)] = run;
         run += v[k];
     }
     if (c == 127u) {
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k4_scatter(const CmFrameDev* __r
     }
     __syncthreads();
     // this tile's row of the column prefix and the bucket totals: asked for now, used behind the ranking
-    const uint2 trow = *reinterpret_cast<const uint2*>(cnt + static_cast<size_t>(tile) * HW + 2 * threadIdx.x);
+    const uint2 trow = *reinterpret_cast<const uint2*>(cnt + cnt_at(tile, 2 * threadIdx.x, gridDim.x));
     const uint4 tot4 = *reinterpret_cast<const uint4*>(totals + 4 * threadIdx.x);
     // (from here on bk[r] = bucket | rank among the wave's records of the bucket << 16)
 #pragma unroll

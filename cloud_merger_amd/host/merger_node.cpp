@@ -221,8 +221,8 @@ int CloudMergerNode::spin_once_pipelined(cm_result* res) {
     const size_t cap_bytes = static_cast<size_t>(cfg_.max_points_total) * msg.point_step;
     if (msg.data.capacity() < cap_bytes || pipe_registered_[pipe_cur_] != msg.data.data()) {
         if (pipe_registered_[pipe_cur_]) { (void)cm_host_unregister(pipe_registered_[pipe_cur_]); pipe_registered_[pipe_cur_] = nullptr; }
-        msg.data.reserve(cap_bytes);
-        msg.data.resize(1);                                             // (data() of an empty vector need not be its buffer)
+        msg.data.resize(cap_bytes);                                     // (every page touched once before it is pinned)
+        msg.data.resize(1);                                             // (capacity stays; data() of an empty vector need not be its buffer)
         if (cm_host_register(msg.data.data(), cap_bytes) == CM_OK) pipe_registered_[pipe_cur_] = msg.data.data();
     }
     msg.height = 1; msg.width = static_cast<uint32_t>(r.n_out);

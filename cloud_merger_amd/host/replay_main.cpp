@@ -56,6 +56,13 @@ int main(int argc, char** argv) {
         else if (k == "--realtime") realtime = true;
         else if (k == "--threads") threads = true;
         else if (k == "--pipeline") cfg.pipelined_publish = true;   // publish frame n - 1 while frame n computes (merger_node.hpp)
+        else if (k == "--live") {                                  // the live node's own configuration (pc_preprocessing_main.cpp): six sensors,
+            const bool pp = cfg.pipelined_publish;                  // ROI, 10 cm, min 2 points, zone-wise ground removal + per-slab outlier filter
+            cfg = live_node_config();
+            cfg.pipelined_publish = pp;
+            n_sensors = static_cast<int>(cfg.sensors.size());
+            have_config = true;
+        }
         else if (k == "--repeat") repeat = std::max(1, std::atoi(next()));      // --threads: play the sequence this many times (the first pass is the warm-up: not timed)
         else if (k == "--leaf") { const float v = std::strtof(next(), nullptr); cfg.params.leaf[0] = cfg.params.leaf[1] = cfg.params.leaf[2] = v; }
         else if (k == "--min-pts") cfg.params.min_points_per_voxel = static_cast<uint32_t>(std::atoi(next()));
@@ -110,7 +117,8 @@ int main(int argc, char** argv) {
     // frames handed to spin_once whose voxel cloud has not been published yet, oldest first (with --pipeline a frame is
     // published during the NEXT spin_once, or by flush())
     std::deque<int> unpublished;
-    node.set_publisher([&](const std::string&, const PointCloud2& msg) {
+    node.set_publisher([&](const std::string& topic, const PointCloud2& msg) {
+        if (topic != cfg.voxel_topic) return;                  // (--live also publishes the no-ground and ground clouds)
         voxels += msg.num_points();
         const int pub_frame = unpublished.empty() ? cur_frame : unpublished.front();
         if (!unpublished.empty()) unpublished.pop_front();
@@ -180,6 +188,9 @@ int main(int argc, char** argv) {
     const auto t0 = std::chrono::steady_clock::now();
     double t_gpu = 0;
     int done = 0;
+    std::vector<double> tick_ms;                               // callbacks + loop body of every tick (host buffers in, message out)
+    double t_steady = 0, slowest_ms = 0;
+    int slowest_tick = -1;
     for (int f = rank; f < n_frames; f += world) {
         cur_frame = f;
         for (int s = 0; s < n_sensors; ++s) {
@@ -195,16 +206,25 @@ int main(int argc, char** argv) {
         cm_result r{};
         unpublished.push_back(f);
         const int st = node.spin_once(&r);
-        t_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - g0).count();
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - g0).count();
+        t_gpu += dt;
+        if (done >= 5) { tick_ms.push_back(1e3 * dt); t_steady += dt; }   // (the first ticks allocate, bootstrap, register buffers)
+        if (done >= 5 && 1e3 * dt > slowest_ms) { slowest_ms = 1e3 * dt; slowest_tick = done; }
         if (st < 0 || st == CM_NOT_READY) { std::fprintf(stderr, "frame %d: %s\n", f, cm_status_string(st)); return 1; }
         ++done;
         if (realtime) std::this_thread::sleep_until(t0 + std::chrono::duration<double>(done / rate));
     }
     node.flush();
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::sort(tick_ms.begin(), tick_ms.end());
+    const double p50 = tick_ms.empty() ? 0.0 : tick_ms[tick_ms.size() / 2];
+    const double p99 = tick_ms.empty() ? 0.0 : tick_ms[std::min(tick_ms.size() - 1, static_cast<size_t>(0.99 * tick_ms.size()))];
     std::printf("{\"rank\": %d, \"world\": %d, \"frames\": %d, \"points_in\": %llu, \"voxels_out\": %llu, "
-                "\"wall_s\": %.6f, \"submit_merge_publish_s\": %.6f, \"frames_per_s\": %.2f, \"points_per_s\": %.3e}\n",
+                "\"wall_s\": %.6f, \"submit_merge_publish_s\": %.6f, \"frames_per_s\": %.2f, \"points_per_s\": %.3e, "
+                "\"tick_ms_p50\": %.4f, \"tick_ms_p99\": %.4f, \"slowest_tick\": %d, \"steady_frames_per_s\": %.2f, "
+                "\"mode\": \"one thread: callbacks, fuse, publish%s\"}\n",
                 rank, world, done, static_cast<unsigned long long>(points), static_cast<unsigned long long>(voxels), wall,
-                t_gpu, done / t_gpu, points / t_gpu);
+                t_gpu, done / t_gpu, points / t_gpu, p50, p99, slowest_tick, tick_ms.empty() ? 0.0 : tick_ms.size() / t_steady,
+                cfg.pipelined_publish ? " (pipelined)" : "");
     return 0;
 }
