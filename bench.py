@@ -285,9 +285,12 @@ def main():
         c.set_stream(streams[q].cuda_stream)
         cms.append(c)
 
+    def jumps(i):
+        return dev_wide is not None and i % args.jump_every == args.jump_every - 1
+
     def pick(i):
         """frame of step i: (host descriptors, device tensors)"""
-        if dev_wide is not None and i % args.jump_every == args.jump_every - 1:
+        if jumps(i):
             return wide, dev_wide
         return frames[i % K], dev_frames[i % K]
 
@@ -298,7 +301,7 @@ def main():
             c.submit_device(k, dv[k].data_ptr(), s.n, s.point_step, s.off_x, s.off_y, s.off_z, s.off_i)
         c.merge_voxelize_async(cparams)
 
-    stats = {"redone": 0, "packed": 0, "quantile": 0, "lat": [], "done_t": []}
+    stats = {"redone": 0, "packed": 0, "quantile": 0, "jumped": 0, "lat": [], "done_t": []}
 
     def run_steps(n, first=0, record=False):
         """n complete frames; at most `inflight` enqueued at any time; every frame's result is waited for."""
@@ -312,6 +315,7 @@ def main():
             if res.status != capi.OK:
                 raise SystemExit(f"frame status {capi.status_string(res.status)}")
             if record:
+                stats["jumped"] += 1 if jumps(first + done) else 0
                 now = time.perf_counter()
                 stats["lat"].append(now - t_enq[done]); stats["done_t"].append(now)
                 stats["redone"] += 1 if res.path_flags & capi.PATH_REDONE else 0
@@ -365,8 +369,12 @@ def main():
                    "min_points_per_voxel": args.min_pts, "sharding": f"frame-sharded x{world}, no collective",
                    "inputs": "resident in HBM (16-byte XYZI records)",
                    "stream": (f"moving: {K} distinct frames per rank ({K * n_in * 16 >> 20} MiB of input, more than the 256 MiB "
-                              f"Infinity Cache), poses and bounds jittered from frame to frame, every {args.jump_every}th frame "
-                              "reaches 30 % further out than the box predicted from its predecessors") if moving else
+                              f"Infinity Cache), poses and bounds jittered from frame to frame; "
+                              + (f"{stats['jumped']} of the {args.steps} timed frames reached 30 % further out than the box predicted from "
+                                 f"their predecessors (every {args.jump_every}th frame of the stream does)" if stats["jumped"] else
+                                 f"none of the {args.steps} timed frames left its predicted box (every {args.jump_every}th frame of the stream "
+                                 "does: the timed window is shorter than that; what such a frame costs is config.box_miss_frame_ms)"
+                                 if (dev_wide is not None) else "no frame leaves its predicted box (--jump-every 0)")) if moving else
                              "static: the same frame resubmitted every step",
                    "frames_in_flight": inflight,
                    "redone_frames": stats["redone"], "packed_frames": stats["packed"], "quantile_frames": stats["quantile"],
@@ -410,6 +418,27 @@ def main():
                 lat1.append(tb - ta); dev1.append(e0.elapsed_time(e1))
         out["config"]["latency_one_frame_ms"] = {"host_enqueue_to_result": 1e3 * float(np.median(lat1)),
                                                  "device_first_kernel_to_last": float(np.median(dev1))}
+        if dev_wide is not None:
+            # What a frame that leaves the predicted box costs (found out on the device, redone inside cm_wait in a box around
+            # the bounds the first attempt measured) and what the frame behind it costs (its splitters are the wide frame's:
+            # usually handed back once more): host-observed, nothing else in flight.
+            miss, after = [], []
+            for it in range(6):
+                for fr, dv, sink in ((frames[0], dev_frames[0], None), (frames[1 % K], dev_frames[1 % K], None),
+                                     (wide, dev_wide, miss), (frames[2 % K], dev_frames[2 % K], after)):
+                    for k, s in enumerate(fr):
+                        c0.set_transform(k, s.q_xyzw, s.t_xyz)
+                        c0.submit_device(k, dv[k].data_ptr(), s.n, s.point_step, s.off_x, s.off_y, s.off_z, s.off_i)
+                    torch.cuda.synchronize()
+                    ta = time.perf_counter()
+                    c0.merge_voxelize_async(cparams)
+                    rr = c0.wait()
+                    if sink is not None and it >= 1:
+                        sink.append((time.perf_counter() - ta, bool(rr.path_flags & capi.PATH_REDONE)))
+            out["config"]["box_miss_frame_ms"] = {
+                "frame_that_leaves_the_box": 1e3 * float(np.median([t for t, _ in miss])), "redone": all(r for _, r in miss),
+                "frame_behind_it": 1e3 * float(np.median([t for t, _ in after])), "frame_behind_it_redone": sum(r for _, r in after) / len(after),
+                "note": "enqueue -> result on the host, one frame at a time; compare latency_one_frame_ms.host_enqueue_to_result"}
 
         # Per-kernel HIP-event timing on the same stream, same inputs (separate frames so the event
         # records do not sit inside the throughput measurement above).

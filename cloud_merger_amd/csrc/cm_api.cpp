@@ -200,6 +200,7 @@ struct cm_ctx {
     size_t prof_used = 0;
     cm_stage_times stage_times;
 
+    std::mutex err_mu;
     std::string err;
 };
 
@@ -221,8 +222,10 @@ const char* k_status_names(int s) {
     }
 }
 
+// (subscriber threads and the loop thread may fail at the same time — an oversize cloud beside a refused merge — and a third
+// thread may be reading the text: the string is only touched under its own lock, and cm_last_error hands out a copy)
 int fail(cm_ctx* c, int code, const std::string& what) {
-    if (c) c->err = what;
+    if (c) { std::lock_guard<std::mutex> lk(c->err_mu); c->err = what; }
     return code;
 }
 
@@ -1304,7 +1307,13 @@ extern "C" {
 
 int cm_version(void) { return CM_VERSION; }
 const char* cm_status_string(int status) { return k_status_names(status); }
-const char* cm_last_error(cm_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+const char* cm_last_error(cm_ctx* ctx) {
+    if (!ctx) return "null context";
+    static thread_local std::string copy;              // valid until the calling thread asks again
+    std::lock_guard<std::mutex> lk(ctx->err_mu);
+    copy = ctx->err;
+    return copy.c_str();
+}
 
 int cm_create(cm_ctx** out, int device, const cm_limits* lim) {
     if (!out || !lim) return CM_BAD_ARG;

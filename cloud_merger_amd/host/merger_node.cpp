@@ -146,7 +146,7 @@ bool load_config(const std::string& path, NodeConfig* cfg, std::string* err) {
 
 CloudMergerNode::CloudMergerNode(const NodeConfig& cfg)
     : cfg_(cfg), have_tf_(cfg.sensors.size()), stamp_ns_(cfg.sensors.size()), submitted_(cfg.sensors.size()),
-      consumed_(cfg.sensors.size()) {
+      consumed_(cfg.sensors.size()), slot_mu_(cfg.sensors.size()) {
     for (auto& f : have_tf_) f.store(false);
     for (auto& t : stamp_ns_) t.store(0);
     for (auto& f : submitted_) f.store(0);
@@ -268,6 +268,7 @@ int CloudMergerNode::on_cloud(size_t sensor, const PointCloud2& msg, bool* accep
     if (!transforms_ready()) return CM_NOT_READY;
     const XyziLayout l = find_xyzi(msg);
     if (!l.ok) { set_error(l.error); return CM_BAD_ARG; }
+    std::lock_guard<std::mutex> lk(slot_mu_[sensor]);
     const int st = cm_submit_cloud(ctx_, static_cast<uint32_t>(sensor), msg.data.data(),
                                    static_cast<uint32_t>(msg.num_points()), msg.point_step, l.off_x, l.off_y, l.off_z, l.off_i);
     if (st == CM_OK) { stamp_ns_[sensor].store(msg.header.stamp_ns); submitted_[sensor].fetch_add(1); }   // CM_SKIPPED: the slot keeps its older cloud
@@ -291,6 +292,7 @@ int CloudMergerNode::spin_once(cm_result* res) {
             hi = std::max(hi, t);
         }
         if (complete && hi - lo > cfg_.max_stamp_spread_ns) {
+            std::lock_guard<std::mutex> lk(slot_mu_[oldest]);          // (no callback of that sensor between the clear and the reset)
             cm_clear_sensor(ctx_, static_cast<uint32_t>(oldest));
             consumed_[oldest].store(submitted_[oldest].load());
             stamp_ns_[oldest].store(0);

@@ -145,6 +145,9 @@ private:
     std::vector<std::atomic<uint64_t>> submitted_, consumed_;
     bool fresh(size_t s) const { return submitted_[s].load() > consumed_[s].load(); }
     std::atomic<uint64_t> dropped_{0};
+    // one lock per sensor: a callback's submit + bookkeeping and the loop thread's drop of that sensor's cloud (approximate
+    // time synchronisation) exclude each other, so a cloud accepted in between is neither marked consumed nor loses its stamp
+    std::vector<std::mutex> slot_mu_;
 };
 
 }  // namespace cloudmerge

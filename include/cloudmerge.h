@@ -110,7 +110,11 @@ typedef struct cm_result {
 #define CM_PATH_PACKED 16u    /* bucket path, crop box that dropped most of the last frame's points: the survivors' records were
                                   packed while counting, so the raw clouds were read once instead of twice */
 #define CM_PATH_SPLIT 32u      /* bucket path, finish by k3_local + k3_compact (tiles stage their centroids, a second launch
-                                  packs them: no look-back between tiles); otherwise k2_local */
+                                  packs them: no look-back between tiles); otherwise k2_local. Summation order: a voxel of up
+                                  to 17 points is added one point after the other in (sensor, point) order — pcl::VoxelGrid's
+                                  own sum, bit for bit given that tie order; a longer one may be finished 64 points per step in
+                                  a fixed tree order (deterministic, within 1e-4 m of the one-after-the-other sum, closer to the
+                                  exact mean). CM_FINISH=v2 (k2_local) adds every voxel one after the other. */
 #define CM_PATH_QUANTILE 64u   /* bucket path, ONE global pass (sort_passes == 1) into buckets cut at the quantiles of the previous
                                   frame's sorted records (same grid), one finish workgroup per bucket; bucket sizes are verified
                                   on the device, a frame whose buckets outgrew the finish is redone with the fixed-grid passes

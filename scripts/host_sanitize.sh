@@ -25,12 +25,12 @@ done
 # ---- HIP library: kernels as usual, the C-ABI host file under TSan
 CSRC=cloud_merger_amd/csrc
 FLAGS="--offload-arch=gfx950 -O2 -g -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fvisibility=hidden -I $CSRC"
-for f in cm_kernels cm_kernels_v2 cm_kernels_v3 cm_kernels_ground; do
+for f in cm_kernels cm_kernels_v2 cm_kernels_v3 cm_kernels_v4 cm_kernels_ground; do
   /opt/rocm/bin/hipcc $FLAGS -c $CSRC/$f.hip -o $OUT/$f.o
 done
 /opt/rocm/bin/hipcc $FLAGS -fsanitize=thread -fno-omit-frame-pointer -c $CSRC/cm_api.cpp -o $OUT/cm_api.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fsanitize=thread -o $OUT/libcloudmerge_hip.so $OUT/cm_kernels.o $OUT/cm_kernels_v2.o \
-    $OUT/cm_kernels_v3.o $OUT/cm_kernels_ground.o $OUT/cm_api.o -Wl,-rpath,/opt/rocm/lib
+    $OUT/cm_kernels_v3.o $OUT/cm_kernels_v4.o $OUT/cm_kernels_ground.o $OUT/cm_api.o -Wl,-rpath,/opt/rocm/lib
 echo "libcloudmerge_hip.so built with cm_api.cpp under -fsanitize=thread"
 HOST=cloud_merger_amd/host
 /opt/rocm/llvm/bin/clang++ -O1 -g -std=c++17 -pthread -fsanitize=thread -fno-omit-frame-pointer -ffp-contract=off \

@@ -4,7 +4,7 @@
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${ISA_OUT:-/tmp/isa}
 mkdir -p $OUT
-STEMS=${@:-cm_kernels_v2 cm_kernels_v3}
+STEMS=${@:-cm_kernels_v2 cm_kernels_v3 cm_kernels_v4}
 for f in $STEMS; do
   (cd $OUT && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -Wno-bitwise-instead-of-logical \
     -I $ROOT/cloud_merger_amd/csrc -c $ROOT/cloud_merger_amd/csrc/$f.hip -o $OUT/$f.o -save-temps=obj 2>/dev/null)

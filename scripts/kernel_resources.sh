@@ -2,7 +2,7 @@
 # Prints VGPR / scratch / occupancy / LDS per kernel of every kernel file (hipcc -Rpass-analysis=kernel-resource-usage);
 # cross-compiles, needs no GPU. usage: bash scripts/kernel_resources.sh > profiles/rN_kernel_resources.txt
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-for f in cm_kernels cm_kernels_v2 cm_kernels_v3 cm_kernels_ground; do
+for f in cm_kernels cm_kernels_v2 cm_kernels_v3 cm_kernels_v4 cm_kernels_ground; do
   echo "== $f.hip"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math \
     -I $ROOT/cloud_merger_amd/csrc -c $ROOT/cloud_merger_amd/csrc/$f.hip -o /tmp/k_$f.o \

@@ -853,6 +853,54 @@ def test_shipped_library_ignores_the_test_hook(sort_path, monkeypatch):
     assert not g["res"].path_flags & REDONE
 
 
+def test_long_voxels_of_the_default_finish_against_the_exact_mean(sort_path, monkeypatch):
+    """k3_local adds voxels of more than 17 points 64 at a time in a fixed tree order (per wave, or — a tile of one
+    or two huge voxels — by all eight waves together), not one point after the other like pcl. Voxels of 18 ... 5000 points,
+    many of them straddling tile boundaries: the default finish, the sequential one (CM_FINISH=v2) and the oracle all lie
+    within 1e-4 m of the exact fp64 mean, the two finishes within 5e-5 m of each other, and the default finish gives the
+    same bits on a second run."""
+    if sort_path == "classic":
+        pytest.skip("bucket path only")
+    rng = np.random.default_rng(77)
+    sizes = np.concatenate([rng.integers(18, 64, 300), rng.integers(64, 600, 200), rng.integers(600, 5000, 12)])
+    centres = rng.uniform(-18, 18, (len(sizes), 3))
+    pts = np.concatenate([c + rng.uniform(0.002, 0.046, (n, 3)) - np.mod(c, 0.05) for c, n in zip(centres, sizes)])
+    pts = np.concatenate([pts, rng.uniform(-20, 20, (60_000, 3))]).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    sensors = [xyzi_cloud(pts, rng.uniform(0, 50, len(pts)))]
+    params = MergeParams(leaf=(0.05,) * 3, min_points_per_voxel=2)
+    st, merged, out, rep = oracle.merge_voxelize(sensors, params, stable=True)
+    assert st == oracle.OK and (rep.counts > 17).sum() >= 400
+    results = {}
+    for finish in ("", "", "v2"):
+        monkeypatch.setenv("CM_FINISH", finish)
+        with capi.CloudMerger(max_points_total=len(pts), max_sensors=1, flags=capi.FLAG_OCCUPANCY) as cm:
+            for _ in range(2):                           # (the second frame: predicted box, bucket path)
+                g = run_gpu(sensors, params, want_merged=False, cm=cm)
+        assert np.array_equal(g["cells"], rep.cells) and np.array_equal(g["counts"], rep.counts)
+        results.setdefault(finish, []).append(g)
+    if not results[""][0]["res"].path_flags & BUCKET:
+        pytest.skip("no bucket path on this device")
+    a, a2, b = results[""][0]["out"], results[""][1]["out"], results["v2"][0]["out"]
+    assert same_bits(a, a2), "deterministic"
+    long_ = rep.counts > 17
+    # exact mean of every long voxel from the merged cloud
+    m64 = xyzi_of(merged).astype(np.float64)
+    cells = oracle.voxel_cells(merged, params.leaf).astype(np.int64)
+    key = (cells[:, 2] * 4096 + cells[:, 1]) * 4096 + cells[:, 0]
+    vk = (rep.cells[:, 2].astype(np.int64) * 4096 + rep.cells[:, 1]) * 4096 + rep.cells[:, 0]
+    order = np.argsort(key, kind="stable")
+    pos = np.searchsorted(key[order], vk)
+    ends = pos + rep.counts
+    csum = np.concatenate([np.zeros((1, 3)), np.cumsum(m64[order][:, :3], axis=0)])
+    exact = (csum[ends] - csum[pos]) / rep.counts[:, None]
+    for name, got in (("k3_local", a), ("k2_local", b), ("oracle", xyzi_of(out))):
+        d = np.abs(got[long_][:, :3].astype(np.float64) - exact[long_]).max()
+        assert d <= 1e-4, f"{name}: {d} m off the exact mean"
+    assert np.abs(a[long_][:, :3].astype(np.float64) - b[long_][:, :3].astype(np.float64)).max() <= 5e-5
+    assert same_bits(b, xyzi_of(out)), "k2_local adds every voxel one after the other: the oracle's bits"
+
+
 @pytest.mark.parametrize("min_pts", [0, 2, 3])
 def test_both_finish_kernels_agree_with_the_oracle(min_pts, sort_path, monkeypatch):
     """The bucket path's finish exists twice: k3_local + k3_compact (default, CM_PATH_SPLIT) and k2_local with its
