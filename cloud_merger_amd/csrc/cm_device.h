@@ -35,19 +35,23 @@
 
 // Quantile passes (cm_kernels_v4.hip): ONE global pass into up to CM4_BINS buckets cut at the quantiles of the previous
 // frame's sorted records (about CM4_TARGET records each), one finish workgroup per bucket (room for CM4_CAP records).
-#define CM4_BINS 2048
+#define CM4_BINS 2048         // bins of the wide pass
+#define CM4_MAX_BUCKETS 8192  // buckets of a frame: above CM4_BINS the wide pass scatters by the low eleven bits of the bucket number
+                              // and a second, narrow pass by the high ones (frames of up to 15 M records)
 #define CM4_TARGET 1920u
 #define CM4_CAP 4032u
 #define CM4_MAX_AVG 2600u     // the host takes the path only while records / buckets stays below this
-#define CM4_MAX_TILES 1536u   // ... and the frame has at most this many 4096-slot tiles (k4_colscan's register tile)
+#define CM4_MAX_TILES 4096u   // ... and the frame has at most this many 4096-slot tiles (k4_colscan's register tile)
 // Buckets the NEXT frame uses when this one sorted n records (the finish writes that many splitters; the host sizes the grids).
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
 static inline uint32_t cm_quant_buckets(uint32_t n) {
     if (n == 0) return 0;
-    const uint32_t b = (n + CM4_TARGET - 1u) / CM4_TARGET;
-    return b > CM4_BINS ? CM4_BINS : b;
+    uint32_t b = (n + CM4_TARGET - 1u) / CM4_TARGET;
+    // one pass for as long as CM4_BINS buckets of at most CM4_MAX_AVG records hold the frame (cfg2: 2048 x 1953)
+    if (b > CM4_BINS && (n + CM4_BINS - 1u) / CM4_BINS <= CM4_MAX_AVG) b = CM4_BINS;
+    return b > CM4_MAX_BUCKETS ? CM4_MAX_BUCKETS : b;
 }
 
 // Point layouts the loaders special-case.

@@ -69,7 +69,7 @@ void cmk2_local_sort(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint
 // ---- voxel finish of the bucket path, second generation (cm_kernels_v3.hip): k3_local + k3_compact
 // tile_info: one uint2 per 2048-record tile; grp_cnt: one zeroed word per 64 tiles; stage: 16 B (32 B: partial) per record slot
 // spl / bofs / n_buckets: the records are grouped by quantile bucket (cm_kernels_v4.hip): one workgroup per bucket;
-// spl_next: where the finish leaves the next frame's splitters (CM4_BINS + 1 words; nullptr: none)
+// spl_next: where the finish leaves the next frame's splitters (CM4_MAX_BUCKETS + 1 words; nullptr: none)
 void cmk3_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* host_state, const void* rec, void* tile_info,
                 uint32_t* grp_cnt, void* stage, uint32_t* stage_key, uint32_t* stage_cnt, bool partial, uint32_t low_bits,
                 uint32_t n_slots,                          // n_slots / 2048 workgroups (n_padded, or what the records are expected to need)
@@ -79,16 +79,21 @@ void cmk3_compact(hipStream_t s, const CmFrameState* st, CmFrameState* st_next, 
                   uint32_t* out_key, uint32_t* out_cnt, bool partial, uint32_t n_padded, uint32_t n_buckets = 0);
 
 // ---- quantile passes (cm_kernels_v4.hip): one global pass into balanced buckets, then k3_local per bucket
-// spl: CM4_BINS + 1 splitters (ascending indices, spl[0] = 0, 0xFFFFFFFF beyond the frame's buckets); cnt: n_tiles rows of
+// spl: CM4_MAX_BUCKETS + 1 splitters (ascending indices, spl[0] = 0, 0xFFFFFFFF beyond the frame's buckets); cnt: n_tiles rows of
 // CM4_BINS 16-bit counters; totals: CM4_BINS words; bofs: CM4_BINS + 1 words (first record of every bucket, total)
 void cmk4_hist(hipStream_t s, const CmFrameDev& f, CmFrameDev* fd, CmTileDev* tiles, bool do_setup, CmFrameState* st,
                const uint32_t* spl, uint32_t* cnt, uint16_t* bid, unsigned long long* tile_state, uint32_t n_tile_state, float* records,
-               int grid_mode, int check_box, uint32_t n_tiles);       // bid: the bucket of every padded slot (0xFFFF: no record)
+               int grid_mode, int check_box, uint32_t n_tiles,        // bid: the bucket of every padded slot (0xFFFF: no record)
+               uint32_t n_buckets, uint32_t* grp_clear, uint32_t n_grp_clear);   // (> CM4_BINS buckets: the second pass's group totals are cleared here)
 void cmk4_colscan(hipStream_t s, CmFrameState* st, uint32_t* host_state, uint32_t* cnt, uint32_t* totals, uint32_t n_tiles,
                   uint32_t cap);
 void cmk4_scatter(hipStream_t s, const CmFrameDev* fd, const CmTileDev* tiles, CmFrameState* st, const uint16_t* bid,
                   const uint32_t* cnt, const uint32_t* totals, uint32_t* bofs, uint32_t n_buckets, void* rec_out,
-                  const float* records, uint32_t n_records, int fold, uint32_t* tile_kept, uint32_t n_tiles);
+                  const float* records, uint32_t n_records, int fold, uint32_t* tile_kept, uint32_t n_tiles,
+                  unsigned char* dig_out);                             // (> CM4_BINS buckets: the high part of every record's bucket number)
+// two passes: where every bucket starts once the second pass has run (bofs_lo: what cmk4_scatter left; idtot: CM4_MAX_BUCKETS words)
+void cmk4_bucket_starts(hipStream_t s, CmFrameState* st, uint32_t* host_state, const uint32_t* bofs_lo, const unsigned char* dig,
+                        uint32_t* idtot, uint32_t* bofs, uint32_t n_buckets, uint32_t cap);
 
 // ---- zone-wise ground removal (cm_kernels_ground.hip) ------------------------------------------
 void cmkg_setup(hipStream_t s, const CmGroundDev& g, CmGroundDev* d_ground);

@@ -345,7 +345,7 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
             }
         }
         if (tile == 0)
-            for (uint32_t j = bn + threadIdx.x; j <= CM4_BINS; j += LBLOCK) spl_next[j] = 0xFFFFFFFFu;
+            for (uint32_t j = bn + threadIdx.x; j <= CM4_MAX_BUCKETS; j += LBLOCK) spl_next[j] = 0xFFFFFFFFu;
     }
 
     // ---- voxels. Thread t takes the sorted positions [t*per, (t+1)*per). A head is a position whose key differs from

@@ -56,29 +56,33 @@ __device__ __forceinline__ uint32_t block_excl_scan4(uint32_t v, uint32_t* lds, 
 // over the banks — the same search over the sorted array reads addresses that are multiples of the step, i.e. ONE bank for
 // every step of 32 or more and a few for the smaller ones (k4_hist 40 us against 19 us for k2_hist0 when it was written
 // that way). Eight searches side by side.
-static_assert(CM4_BINS == 2048, "eleven levels");
+static_assert(CM4_BINS == 2048 && CM4_MAX_BUCKETS == 8192, "eleven to thirteen levels");
 // (nodes numbered from 1, heap fashion: children of node b are 2b and 2b + 1, so a step is b = 2b + (tree[b] <= key) — one
-// add-with-carry behind the compare; word 0 of the tree is unused. After eleven steps b - 2048 is the bucket.)
+// add-with-carry behind the compare; word 0 of the tree is unused. After LEVELS steps b - 2^LEVELS is the bucket.)
+// LEVELS = 11: up to 2048 buckets, one global pass. 12, 13: up to 8192 buckets for frames of up to 15 M records — the pass
+// then scatters by the low eleven bits of the bucket number and a second, narrow pass (k2_scatter by the byte this one
+// leaves beside every record) by the high ones: a stable LSD sort by bucket, two passes where the fixed grid takes three.
+template <int LEVELS>
 __device__ __forceinline__ void load_splitter_tree(uint32_t* __restrict__ tree, const uint32_t* __restrict__ spl_g) {
 #pragma unroll
-    for (int q = 0; q < CM4_BINS / CM2_BLOCK; ++q) {
-        const uint32_t e = q * CM2_BLOCK + threadIdx.x;            // node e (1 .. 2047)
+    for (int q = 0; q < (1 << LEVELS) / CM2_BLOCK; ++q) {
+        const uint32_t e = q * CM2_BLOCK + threadIdx.x;            // node e (1 .. 2^LEVELS - 1)
         const uint32_t l = 31u - static_cast<uint32_t>(__builtin_clz(e | 1u));
         const uint32_t p = e - (1u << l);
-        tree[e] = e ? spl_g[((2u * p + 1u) << (10u - l))] : 0u;
+        tree[e] = e ? spl_g[((2u * p + 1u) << (LEVELS - 1 - l))] : 0u;
     }
 }
-template <int N>
+template <int LEVELS, int N>
 __device__ __forceinline__ void buckets_of(const uint32_t* __restrict__ tree, const uint32_t (&key)[N], uint32_t (&bk)[N]) {
 #pragma unroll
     for (int r = 0; r < N; ++r) bk[r] = 1;
 #pragma unroll
-    for (int l = 0; l < 11; ++l) {
+    for (int l = 0; l < LEVELS; ++l) {
 #pragma unroll
         for (int r = 0; r < N; ++r) bk[r] = bk[r] + bk[r] + ((tree[bk[r]] <= key[r]) ? 1u : 0u);
     }
 #pragma unroll
-    for (int r = 0; r < N; ++r) bk[r] -= CM4_BINS;
+    for (int r = 0; r < N; ++r) bk[r] -= 1u << LEVELS;
 }
 
 // Where counter word `word` (two 16-bit bucket counters) of tile `tile` lives: column blocks of eight words, the tiles of a
@@ -135,13 +139,15 @@ __device__ __forceinline__ void fold_bounds4(float* s_f, CmFrameState* __restric
 // k4_hist: what k2_hist0 does for the fixed-grid passes (frame set-up, clears, box check, min/max records), with the
 // counts taken per quantile bucket: row `tile` of cnt = CM4_BINS 16-bit counters (a tile holds 4096 points: no overflow).
 // ------------------------------------------------------------------------------------------------
+template <int LEVELS>
 __global__ __launch_bounds__(CM2_BLOCK) void k4_hist(const CmFrameDev fv, CmFrameDev* __restrict__ fd_dst,
                                                      CmTileDev* __restrict__ tiles_dst, int do_setup,
                                                      CmFrameState* __restrict__ st, const uint32_t* __restrict__ spl_g,
                                                      uint32_t* __restrict__ cnt, uint16_t* __restrict__ bid,
                                                      unsigned long long* __restrict__ tile_state, uint32_t n_tile_state,
-                                                     float* __restrict__ records, int grid_mode, int check_box) {
-    __shared__ uint32_t spl[CM4_BINS];
+                                                     float* __restrict__ records, int grid_mode, int check_box,
+                                                     uint32_t* __restrict__ grp_clear, uint32_t n_grp_clear, uint32_t n_passes) {
+    __shared__ uint32_t spl[1 << LEVELS];
     __shared__ uint32_t lh[CM4_BINS / 2];
     __shared__ float s_mm[CM2_WAVES][6];
     __shared__ uint32_t s_cnt[CM2_WAVES];
@@ -166,6 +172,8 @@ __global__ __launch_bounds__(CM2_BLOCK) void k4_hist(const CmFrameDev fv, CmFram
             reinterpret_cast<uint32_t*>(fd_dst)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&fv)[threadIdx.x];
     }
     for (uint32_t k = tile * CM2_BLOCK + threadIdx.x; k < n_tile_state; k += gridDim.x * CM2_BLOCK) tile_state[k] = 0ull;
+    // (two passes: the group totals k2_hist accumulates for the second one)
+    for (uint32_t k = tile * CM2_BLOCK + threadIdx.x; k < n_grp_clear; k += gridDim.x * CM2_BLOCK) grp_clear[k] = 0;
     if (tile == 0 && threadIdx.x == 0) {                 // the box and its grid, as the host set them up
         st->status = CM_DEV_OK;
         for (int a = 0; a < 3; ++a) {
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(CM2_BLOCK) void k4_hist(const CmFrameDev fv, CmFram
             st->div_b[a] = db;
         }
         st->key_bits = fd->box_key_bits;
-        st->n_passes = 1;
+        st->n_passes = n_passes;
     }
     const BoxGrid b = box_grid_of(fd);
     const bool predicted = check_box != 0;
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(CM2_BLOCK) void k4_hist(const CmFrameDev fv, CmFram
     const CmSensorDev& sd = fd->s[te.info & 0xFFu];
     Pt p[CM2_ITEMS];
     load_tile_te<CM2_ITEMS>(te, sd, w * (64 * CM2_ITEMS) + lane, p);
-    load_splitter_tree(spl, spl_g);
+    load_splitter_tree<LEVELS>(spl, spl_g);
     float m[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) m[k] = sd.m[k];
@@ -221,13 +229,15 @@ __global__ __launch_bounds__(CM2_BLOCK) void k4_hist(const CmFrameDev fv, CmFram
         okm |= ok ? (1u << r) : 0u;
         keepm |= (ok & in) ? (1u << r) : 0u;
     }
-    buckets_of<CM2_ITEMS>(spl, key, bk);
+    buckets_of<LEVELS, CM2_ITEMS>(spl, key, bk);
     const uint32_t slot0 = tile * CM_TILE + w * (64 * CM2_ITEMS) + lane;
 #pragma unroll
     for (int r = 0; r < CM2_ITEMS; ++r) {
-        // (a slot without a record adds nothing, to a word of its own: same-address LDS adds of a wave serialise)
+        // (a slot without a record adds nothing, to a word of its own: same-address LDS adds of a wave serialise;
+        // the counters are per LOW eleven bits of the bucket number: what this pass scatters by)
         const bool keep = (keepm >> r) & 1u;
-        atomicAdd(&lh[keep ? bk[r] >> 1 : static_cast<uint32_t>(lane)], (keep ? 1u : 0u) << ((bk[r] & 1u) * 16u));
+        const uint32_t lo = bk[r] & (CM4_BINS - 1);
+        atomicAdd(&lh[keep ? lo >> 1 : static_cast<uint32_t>(lane)], (keep ? 1u : 0u) << ((lo & 1u) * 16u));
         // the bucket of every slot (0xFFFF: no record), so that k4_scatter neither tests nor searches a second time
         bid[slot0 + r * 64] = static_cast<uint16_t>(keep ? bk[r] : 0xFFFFu);
     }
@@ -287,8 +297,9 @@ __global__ __launch_bounds__(CM2_BLOCK) void k4_hist(const CmFrameDev fv, CmFram
 // bucket beyond the finish's capacity aborts the frame — its packed prefixes may then have carried into their neighbours,
 // and nothing reads them).
 // ------------------------------------------------------------------------------------------------
-#define CM4_SCAN_TPC 12            // tiles per chunk at most: 128 chunks -> 1536 tiles (6.3 M slots)
-static_assert(CM4_SCAN_TPC * 128 >= CM4_MAX_TILES, "k4_colscan's register tile covers the frames the host sends here");
+// TPC: tiles per chunk at most — 12: 128 chunks -> 1536 tiles (6.3 M slots); 32: 4096 tiles (16.8 M slots)
+static_assert(32 * 128 >= CM4_MAX_TILES, "k4_colscan's register tile covers the frames the host sends here");
+template <int CM4_SCAN_TPC>
 __global__ __launch_bounds__(1024) void k4_colscan(CmFrameState* __restrict__ st, uint32_t* __restrict__ host_state,
                                                    uint32_t* __restrict__ cnt, uint32_t* __restrict__ totals,
                                                    uint32_t n_tiles, uint32_t cap) {
@@ -346,12 +357,16 @@ __global__ __launch_bounds__(1024) void k4_colscan(CmFrameState* __restrict__ st
 // buckets in ascending address order with same-bucket records side by side, which is what lets the XCD's L2 put the
 // 32-byte runs of neighbouring tiles together (file header). Tiles are dealt to the XCDs in contiguous ranges.
 // ------------------------------------------------------------------------------------------------
+template <bool TWO>
 __global__ __launch_bounds__(CM2_BLOCK, 6) void k4_scatter(const CmFrameDev* __restrict__ fd, const CmTileDev* __restrict__ tiles,
                                                            CmFrameState* __restrict__ st, const uint16_t* __restrict__ bid,
                                                            const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ totals,
                                                            uint32_t* __restrict__ bofs, uint32_t n_buckets,
                                                            float4* __restrict__ rec_out, const float* __restrict__ records,
-                                                           uint32_t n_records, int fold, uint32_t* __restrict__ tile_kept) {
+                                                           uint32_t n_records, int fold, uint32_t* __restrict__ tile_kept,
+                                                           unsigned char* __restrict__ dig_out) {
+    // TWO: the bucket numbers have up to thirteen bits; this pass scatters by the low eleven and leaves the high ones as a
+    // byte beside every record (dig_out), for the second pass (k2_hist + k2_scatter<false>: cm_kernels_v2.hip).
     constexpr int HW = CM4_BINS / 2;                      // counter words per wave
     constexpr int STG = 2048;                             // staged records per round
     __shared__ uint32_t buf[STG * 4 + STG / 2];           // per-wave counters (8 x HW) | staging: records + buckets
@@ -402,7 +417,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k4_scatter(const CmFrameDev* __r
             rec[r].z = xf_row(m[8], m[9], m[10], m[11], p[r].x, p[r].y, p[r].z);
             rec[r].w = all_fields ? p[r].i : 0.f;
             vmask |= (bk[r] != 0xFFFFu) ? (1u << r) : 0u;
-            bk[r] &= CM4_BINS - 1;
+            bk[r] &= TWO ? (CM4_MAX_BUCKETS - 1) : (CM4_BINS - 1);
         }
     }
     __syncthreads();
@@ -416,7 +431,8 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k4_scatter(const CmFrameDev* __r
 #pragma unroll
         for (int r = r0; r < r0 + 4; ++r) {
             const bool has = (vmask >> r) & 1u;
-            got[r - r0] = atomicAdd(&wcnt[w][has ? bk[r] >> 1 : static_cast<uint32_t>(lane)], (has ? 1u : 0u) << ((bk[r] & 1u) * 16u));
+            const uint32_t lo = bk[r] & (CM4_BINS - 1);
+            got[r - r0] = atomicAdd(&wcnt[w][has ? lo >> 1 : static_cast<uint32_t>(lane)], (has ? 1u : 0u) << ((lo & 1u) * 16u));
         }
 #pragma unroll
         for (int r = r0; r < r0 + 4; ++r) {
@@ -462,7 +478,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k4_scatter(const CmFrameDev* __r
 #pragma unroll
     for (int r = 0; r < CM2_ITEMS; ++r) {
         const uint32_t bq = bk[r] & 0xFFFFu;
-        const uint32_t wv = wcnt[w][bq >> 1];
+        const uint32_t wv = wcnt[w][(bq & (CM4_BINS - 1)) >> 1];
         const uint32_t at = ((wv >> ((bq & 1u) * 16u)) & 0xFFFFu) + (bk[r] >> 16);
         bk[r] = bq | ((((vmask >> r) & 1u) ? at : 0xFFFFu) << 16);
     }
@@ -481,7 +497,12 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k4_scatter(const CmFrameDev* __r
 #pragma unroll
         for (int j = 0; j < STG / CM2_BLOCK; ++j) {
             const uint32_t t = lo + j * CM2_BLOCK + threadIdx.x;
-            if (t < tile_valid) rec_out[gofs[sbk[t - lo]] + t] = srec[t - lo];
+            if (t < tile_valid) {
+                const uint32_t id = sbk[t - lo];
+                const uint32_t pos = gofs[id & (CM4_BINS - 1)] + t;
+                rec_out[pos] = srec[t - lo];
+                if (TWO) dig_out[pos] = static_cast<unsigned char>(id >> 11);
+            }
         }
     }
     // The exact bounds of the cloud (pcl::getMinMax3D) for the result and for the next frame's box.
@@ -491,21 +512,100 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k4_scatter(const CmFrameDev* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two passes: the finish tiles by bucket, so it needs where every bucket starts once BOTH passes have run. After the first
+// pass the records of low part `lo` sit at [bofs_lo[lo], bofs_lo[lo + 1]) with the high part of their bucket number as a
+// byte each: k4_idcount (one workgroup per low part) counts those bytes -> idtot[hi * 2048 + lo]; k4_idscan turns the
+// totals, in bucket order, into bofs (and refuses a bucket beyond the finish's capacity).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k4_idcount(const CmFrameState* __restrict__ st, const uint32_t* __restrict__ bofs_lo,
+                                                  const unsigned char* __restrict__ dig, uint32_t* __restrict__ idtot, uint32_t n_hi) {
+    __shared__ uint32_t cnt[CM4_MAX_BUCKETS / CM4_BINS];
+    if (st->status != CM_DEV_OK || st->outside || st->quant_abort) return;
+    const uint32_t lo = blockIdx.x;
+    if (threadIdx.x < CM4_MAX_BUCKETS / CM4_BINS) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t a = bofs_lo[lo], e = bofs_lo[lo + 1];
+    uint32_t c[CM4_MAX_BUCKETS / CM4_BINS] = {0, 0, 0, 0};
+    for (uint32_t i = a + threadIdx.x; i < e; i += 256) {
+        const uint32_t h = dig[i];
+#pragma unroll
+        for (uint32_t q = 0; q < CM4_MAX_BUCKETS / CM4_BINS; ++q) c[q] += h == q ? 1u : 0u;
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < CM4_MAX_BUCKETS / CM4_BINS; ++q) {
+        const uint32_t v = wave_sum_u32(c[q]);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&cnt[q], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < n_hi) idtot[threadIdx.x * CM4_BINS + lo] = cnt[threadIdx.x];
+}
+__global__ __launch_bounds__(1024) void k4_idscan(CmFrameState* __restrict__ st, uint32_t* __restrict__ host_state,
+                                                  const uint32_t* __restrict__ idtot, uint32_t* __restrict__ bofs, uint32_t n_ids,
+                                                  uint32_t cap) {
+    __shared__ uint32_t lds[16];
+    if (st->status != CM_DEV_OK || st->outside || st->quant_abort) return;
+    constexpr int PER = CM4_MAX_BUCKETS / 1024;
+    uint32_t v[PER], sum = 0;
+    bool big = false;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const uint32_t i = threadIdx.x * PER + k;
+        v[k] = i < n_ids ? idtot[i] : 0u;
+        big = big || v[k] > cap;
+        sum += v[k];
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan_u32(sum, lane);
+    if (lane == 63) lds[w] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (int q = 0; q < w; ++q) run += lds[q];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const uint32_t i = threadIdx.x * PER + k;
+        if (i <= n_ids) bofs[i] = run;                     // (i == n_ids: the total)
+        run += v[k];
+    }
+    if (big) {                                             // a bucket the finish cannot hold: the frame goes back
+        st->quant_abort = 1u;
+        host_state[offsetof(CmFrameState, err) / 4] = CM_DEV_ERR_QUANT;
+    }
+}
+
 }  // namespace
 
 void cmk4_hist(hipStream_t s, const CmFrameDev& f, CmFrameDev* fd, CmTileDev* tiles, bool do_setup, CmFrameState* st,
                const uint32_t* spl, uint32_t* cnt, uint16_t* bid, unsigned long long* tile_state, uint32_t n_tile_state, float* records,
-               int grid_mode, int check_box, uint32_t n_tiles) {
-    hipLaunchKernelGGL(k4_hist, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, f, fd, tiles, do_setup ? 1 : 0, st, spl, cnt, bid, tile_state,
-                       n_tile_state, records, grid_mode, check_box);
+               int grid_mode, int check_box, uint32_t n_tiles, uint32_t n_buckets, uint32_t* grp_clear, uint32_t n_grp_clear) {
+    const uint32_t np = n_buckets > CM4_BINS ? 2u : 1u;
+#define CM4_HIST(L) hipLaunchKernelGGL(k4_hist<L>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, f, fd, tiles, do_setup ? 1 : 0, st, spl, cnt, bid, \
+                                       tile_state, n_tile_state, records, grid_mode, check_box, grp_clear, n_grp_clear, np)
+    if (n_buckets <= 2048) CM4_HIST(11);
+    else if (n_buckets <= 4096) CM4_HIST(12);
+    else CM4_HIST(13);
+#undef CM4_HIST
 }
 void cmk4_colscan(hipStream_t s, CmFrameState* st, uint32_t* host_state, uint32_t* cnt, uint32_t* totals, uint32_t n_tiles,
                   uint32_t cap) {
-    hipLaunchKernelGGL(k4_colscan, dim3(CM4_BINS / 16), dim3(1024), 0, s, st, host_state, cnt, totals, n_tiles, cap);
+    if (n_tiles <= 12 * 128)
+        hipLaunchKernelGGL(k4_colscan<12>, dim3(CM4_BINS / 16), dim3(1024), 0, s, st, host_state, cnt, totals, n_tiles, cap);
+    else
+        hipLaunchKernelGGL(k4_colscan<32>, dim3(CM4_BINS / 16), dim3(1024), 0, s, st, host_state, cnt, totals, n_tiles, cap);
 }
 void cmk4_scatter(hipStream_t s, const CmFrameDev* fd, const CmTileDev* tiles, CmFrameState* st, const uint16_t* bid,
                   const uint32_t* cnt, const uint32_t* totals, uint32_t* bofs, uint32_t n_buckets, void* rec_out,
-                  const float* records, uint32_t n_records, int fold, uint32_t* tile_kept, uint32_t n_tiles) {
-    hipLaunchKernelGGL(k4_scatter, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, bid, cnt, totals, bofs, n_buckets,
-                       reinterpret_cast<float4*>(rec_out), records, n_records, fold, tile_kept);
+                  const float* records, uint32_t n_records, int fold, uint32_t* tile_kept, uint32_t n_tiles, unsigned char* dig_out) {
+    if (n_buckets > CM4_BINS)
+        hipLaunchKernelGGL(k4_scatter<true>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, bid, cnt, totals, bofs, n_buckets,
+                           reinterpret_cast<float4*>(rec_out), records, n_records, fold, tile_kept, dig_out);
+    else
+        hipLaunchKernelGGL(k4_scatter<false>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, bid, cnt, totals, bofs, n_buckets,
+                           reinterpret_cast<float4*>(rec_out), records, n_records, fold, tile_kept, nullptr);
+}
+void cmk4_bucket_starts(hipStream_t s, CmFrameState* st, uint32_t* host_state, const uint32_t* bofs_lo, const unsigned char* dig,
+                        uint32_t* idtot, uint32_t* bofs, uint32_t n_buckets, uint32_t cap) {
+    const uint32_t n_hi = (n_buckets + CM4_BINS - 1) / CM4_BINS;
+    hipLaunchKernelGGL(k4_idcount, dim3(CM4_BINS), dim3(256), 0, s, st, bofs_lo, dig, idtot, n_hi);
+    hipLaunchKernelGGL(k4_idscan, dim3(1), dim3(1024), 0, s, st, host_state, idtot, bofs, n_hi * CM4_BINS, cap);
 }

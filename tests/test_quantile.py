@@ -133,3 +133,23 @@ def test_switch_off(monkeypatch):
             sensors, params = synth.config2_stream(k, n_per_sensor=n_per, min_pts=2)
             res, _ = frame_against_oracle(cm, sensors, params, 4 * n_per)
             assert not res.path_flags & QUANTILE
+
+
+def test_big_frame_takes_two_quantile_passes(monkeypatch):
+    """cfg3's dense variant at full size (8 x 2 M points, 86 % inside the ROI: 13.7 M records of a 29-bit index): more
+    buckets than the wide pass has bins — it scatters by the low eleven bits of the bucket number, a second, narrow pass
+    by the high ones: two global passes where the fixed grid takes three. CM_QUANT2=1: the variant is off by default (it
+    saves traffic, not time: cm_api.cpp enqueue)."""
+    monkeypatch.setenv("CM_QUANT2", "1")
+    sensors, params = synth.config3_dense(min_pts=2)
+    n = sum(s.n for s in sensors)
+    with capi.CloudMerger(max_points_total=n, max_sensors=len(sensors), flags=capi.FLAG_OCCUPANCY) as cm:
+        seen = []
+        for k in range(4):
+            res, rep = frame_against_oracle(cm, sensors, params, n)
+            needs_lds_rank(res)
+            seen.append((res.sort_passes, bool(res.path_flags & QUANTILE), bool(res.path_flags & REDONE)))
+        # (the first frame overflows a bucket of the two-pass fixed grid and is redone; the second takes three fixed-grid
+        # passes and leaves the splitters; from then on two quantile passes)
+        assert not seen[0][1] and seen[1][0] == 3 and not seen[1][1], seen
+        assert seen[2] == (2, True, False) and seen[3] == (2, True, False), seen
