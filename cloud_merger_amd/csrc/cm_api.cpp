@@ -184,7 +184,9 @@ struct cm_ctx {
     bool last_quant = false;             // the frame in flight runs the quantile passes
     bool wrote_spl = false;              // ... and its finish leaves splitters in spl[spl_cur ^ 1]
     uint32_t quant_off_frames = 0;       // frames for which the fixed-grid passes run although splitters are at hand
-    uint32_t quant_streak = 0, quant_good = 0;   // hand-backs in a row (a good frame or two between them do not end a row); good frames since
+    uint32_t quant_hist = 0;             // the last eight attempts, newest in bit 0: 1 = handed back
+    uint32_t quant_rest = 8;             // how long the next rest is (doubles while rests keep being needed, back to 8 after 16 good frames)
+    uint32_t quant_good = 0;             // good attempts in a row
     int lb_grid_mode = 0, lb_mode = 0;   // the last launch_bucket's arguments (a quantile frame that is handed back is
     uint32_t lb_g = 0, lb_low = 0;       // redone with the fixed-grid passes in the same box)
 
@@ -1166,12 +1168,20 @@ int wait_frame(cm_ctx* c, cm_result* res) {
             const bool quant_fail = c->last_quant && !h0.outside &&
                                     (h0.err == CM_DEV_ERR_QUANT || h0.err == CM_DEV_ERR_UNSORTED || h0.err == CM_DEV_ERR_BUCKET);
             if (quant_fail) {
-                // The redone frame leaves the splitters of THIS scene, so the next frame may try at once: one abrupt change costs one
-                // hand-back. Only when hand-backs keep coming (a scene that flips from frame to frame) do the quantile passes rest:
-                // 4, 16, 64, 256 frames.
-                c->quant_off_frames = c->quant_streak ? std::min<uint32_t>(1u << (2 * c->quant_streak), 256u) : 0u;
-                if (c->quant_streak < 8) ++c->quant_streak;
+                if (getenv("CM_VERBOSE")) std::fprintf(stderr, "[cloudmerge] quantile frame handed back: err %u, n_valid %u, spl_n %u\n", h0.err, h0.n_valid, c->spl_n);
+                // The redone frame leaves the splitters of THIS scene, so the next frame may try at once: an abrupt change costs
+                // one hand-back. A hand-back costs about a quarter of a frame more than the fixed-grid passes alone and a good
+                // attempt saves a sixth, so attempts pay while fewer than one in three fail: the quantile passes only rest —
+                // 8, 16, ... 128 frames — once three of the last eight attempts were handed back (a scene whose dense surfaces
+                // keep moving across voxel layers: the index is z-major, so a ground plane that tilts by half a voxel at range
+                // moves its points to other buckets).
+                c->quant_hist = ((c->quant_hist << 1) | 1u) & 0xFFu;
                 c->quant_good = 0;
+                if (__builtin_popcount(c->quant_hist) >= 3) {
+                    c->quant_off_frames = c->quant_rest;
+                    if (c->quant_rest < 128) c->quant_rest *= 2;
+                    c->quant_hist = 0;
+                }
                 ++c->n_redone;
                 redone = true;
                 c->h_state->err = 0;
@@ -1296,7 +1306,10 @@ int wait_frame(cm_ctx* c, cm_result* res) {
             std::memcpy(c->spl_min_b, c->frame.box_min_b, sizeof c->spl_min_b);
             std::memcpy(c->spl_div_b, c->frame.box_div_b, sizeof c->spl_div_b);
             std::memcpy(c->spl_inv_leaf, c->frame.inv_leaf, sizeof c->spl_inv_leaf);
-            if (c->last_quant && !redone && ++c->quant_good >= 8) c->quant_streak = 0;      // eight good frames in a row: the row of hand-backs is over
+            if (c->last_quant && !redone) {
+                c->quant_hist = (c->quant_hist << 1) & 0xFFu;
+                if (++c->quant_good >= 16) c->quant_rest = 8;
+            }
         }
         if (h.status == CM_OK) {
             r.n_merged = h.n_valid;

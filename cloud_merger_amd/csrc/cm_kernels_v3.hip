@@ -328,24 +328,33 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
     PH3(2);
 
     // ---- the next frame's splitters (cm_kernels_v4.hip): sorted position e of this tile is record base + a + e of the whole
-    // frame in index order; quantile j of bn sits at record floor(j * n / bn). Each is written by the one tile whose range
-    // holds it; tile 0 also writes the fixed ends (splitter 0 = index 0, 0xFFFFFFFF beyond the last bucket).
+    // frame in index order; splitter j of bn is the index at record j * Q, Q = ceil(n / bn) (buckets of Q records; the last
+    // ones may stay empty). Each is written by the one tile whose range holds it; tile 0 also writes the fixed ends (splitter
+    // 0 = index 0, 0xFFFFFFFF from the first bucket without a record on). All of it is wave-uniform 32-bit arithmetic.
     if (!PARTIAL && spl_next) {
         // (a tile whose last voxel runs on beyond its LDS — L = 0 frames only — cannot say which index sits at the positions
         // out there: the frame then leaves no splitters)
         if (tail_open && threadIdx.x == 0) st->spl_incomplete = 1u;
-        const uint32_t bn = cm_quant_buckets(n);
+        // (u32 / u32 by a float reciprocal and a correction step: a handful of instructions where the compiler's exact
+        // division takes twenty-odd, three times per tile — it showed as 5 us on the fixed-grid finish)
+        auto fdiv = [](uint32_t x, uint32_t y) {
+            uint32_t q = static_cast<uint32_t>(static_cast<float>(x) * __frcp_rn(static_cast<float>(y)));
+            while (static_cast<unsigned long long>(q) * y > x) --q;
+            while (static_cast<unsigned long long>(q + 1u) * y <= x) ++q;
+            return q;
+        };
+        const uint32_t bn = SCAL(cm_quant_buckets(n));
+        const uint32_t Q = bn ? SCAL(fdiv(n + bn - 1u, bn)) : 1u;
         if (bn && m) {
-            const unsigned long long g0 = static_cast<unsigned long long>(base) + a, g1 = g0 + m;
-            const uint32_t j_lo = static_cast<uint32_t>((g0 * bn + n - 1ull) / n);
-            for (uint32_t j = j_lo + threadIdx.x; j < bn; j += LBLOCK) {
-                const unsigned long long pj = static_cast<unsigned long long>(j) * n / bn;
-                if (pj >= g1) break;
-                spl_next[j] = j ? sk[si[static_cast<uint32_t>(pj - g0)]] : 0u;
-            }
+            const uint32_t g0 = base + a, g1 = g0 + m;
+            const uint32_t j_lo = SCAL(fdiv(g0 + Q - 1u, Q));
+            for (uint32_t j = j_lo + threadIdx.x; j * Q < g1; j += LBLOCK)          // (g1 <= n: only buckets that hold records)
+                spl_next[j] = j ? sk[si[j * Q - g0]] : 0u;
         }
-        if (tile == 0)
-            for (uint32_t j = bn + threadIdx.x; j <= CM4_MAX_BUCKETS; j += LBLOCK) spl_next[j] = 0xFFFFFFFFu;
+        if (tile == 0) {
+            const uint32_t used = bn ? fdiv(n + Q - 1u, Q) : 0u;                     // buckets that hold records (<= bn)
+            for (uint32_t j = used + threadIdx.x; j <= CM4_MAX_BUCKETS; j += LBLOCK) spl_next[j] = 0xFFFFFFFFu;
+        }
     }
 
     // ---- voxels. Thread t takes the sorted positions [t*per, (t+1)*per). A head is a position whose key differs from
