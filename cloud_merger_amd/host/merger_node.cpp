@@ -2,6 +2,8 @@
 #include "merger_node.hpp"
 
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <fstream>
 #include <sstream>
@@ -198,13 +200,24 @@ void CloudMergerNode::flush() {
 // spin_once with NodeConfig::pipelined_publish: enqueue frame n; while it computes, finish and publish frame n - 1; wait
 // for frame n; start its copy-out (cm_result_publish_async: a stream of its own, double-buffered result) and return.
 int CloudMergerNode::spin_once_pipelined(cm_result* res) {
+    static const bool trace = std::getenv("CM_NODE_TRACE") != nullptr;  // (debugging aid: which call of a slow tick took the time)
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
+    auto t0 = now();
     const int eq = cm_merge_voxelize_async(ctx_, &cfg_.params);        // fusePointclouds + voxelgrid, enqueued
+    const double t_enq = since(t0); t0 = now();
     flush();                                                            // frame n - 1 goes out while frame n runs
+    const double t_flush = since(t0); t0 = now();
+    struct Report { bool on; double a, b; std::chrono::steady_clock::time_point t; double* w; double* p;
+                    ~Report() { if (on && (a > 3 || b > 3 || *w > 3 || *p > 3)) std::fprintf(stderr, "[node] slow tick: enqueue %.2f flush %.2f wait %.2f publish %.2f ms\n", a, b, *w, *p); } };
+    double t_wait = 0, t_pub = 0;
+    Report rep{trace, t_enq, t_flush, t0, &t_wait, &t_pub};
     if (res) *res = cm_result{};
     if (eq == CM_NOT_READY) return eq;                                  // :575 — nothing fused this tick
     if (eq < 0) { set_error(cm_last_error(ctx_)); return eq; }
     cm_result r{};
     const int st = cm_wait(ctx_, &r);
+    t_wait = since(t0); t0 = now();
     if (res) *res = r;
     if (st < 0) { set_error(cm_last_error(ctx_)); return st; }
     {
@@ -240,6 +253,7 @@ int CloudMergerNode::spin_once_pipelined(cm_result* res) {
     msg.header.frame_id = cfg_.base_frame;
     pipe_in_flight_ = true;
     pipe_cur_ ^= 1;
+    t_pub = since(t0);
     return st;
 }
 

@@ -34,8 +34,15 @@ out = {"frames": frames, "unit": "bytes per frame", "kernels": {},
 tot_f = tot_w = 0.0
 for k in sorted(set(res["FETCH_SIZE"]) | set(res["WRITE_SIZE"])):
     if k in ("k_probe_lds_order", "k_setup") or res["FETCH_SIZE"].get(k, {"dispatches": 0})["dispatches"] < frames // 2: continue   # one-off kernels (probe, bootstrap)
-    f = res["FETCH_SIZE"].get(k, {"sum_kb": 0})["sum_kb"] * 1024 / frames
-    w = res["WRITE_SIZE"].get(k, {"sum_kb": 0})["sum_kb"] * 1024 / frames
+    # per frame that ran this kernel: the quantile passes' kernels (k4_*) run on fewer frames than the finish (a context's first
+    # frame takes the fixed-grid passes), and a fixed-grid kernel may be launched two or three times per frame
+    def per_frame(c):
+        r_ = res[c].get(k, {"sum_kb": 0, "dispatches": 0})
+        ref = res[c].get("k4_hist" if k.startswith("k4_") else ("k2_hist0" if (k.startswith("k2_") or k == "k_gscan") else ""), None)
+        nf = ref["dispatches"] if ref and ref["dispatches"] >= frames // 2 else frames
+        return r_["sum_kb"] * 1024 / max(1, nf)
+    f = per_frame("FETCH_SIZE")
+    w = per_frame("WRITE_SIZE")
     out["kernels"][k] = {"fetch_raw": f, "fetch_x2": 2 * f, "write": w}
     tot_f += f; tot_w += w
 out["fetch_raw"] = tot_f; out["fetch_x2"] = 2 * tot_f; out["write"] = tot_w
