@@ -607,8 +607,9 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
         // (one pass: a bin is a bucket and must fit the finish; two: a bin holds the buckets of up to four high parts)
         cmk4_colscan(st, state, c->h_state_dev, c->qcnt, c->qtot, nt, two ? 0xFFFFu : CM4_CAP);
         prof_mark(c, "k4_scatter");
+        const bool ballot = !c->lds_rank;                // ranks by ballots where the returning LDS adds are not (known to be) lane-ordered
         cmk4_scatter(st, c->d_frame, c->d_tiles, state, c->qbid, c->qcnt, c->qtot, c->qbofs, nb, c->rec_a, c->records, nt,
-                     predicted ? 1 : 0, c->d_tile_kept, nt, two ? c->dig : nullptr);
+                     predicted ? 1 : 0, c->d_tile_kept, nt, two ? c->dig : nullptr, ballot);
         const void* rec_sorted = c->rec_a;
         void* stage = c->rec_b;
         const uint32_t* bofs = c->qbofs;
@@ -621,7 +622,7 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
             if (big_p) { prof_mark(c, "k_gscan"); cmk_gscan(st, state, grp1, c->totals, 1, n_groups); }
             prof_mark(c, "k2_scatter");
             cmk2_scatter(st, false, c->d_frame, c->d_tiles, state, c->rec_a, c->rec_b, c->dig, c->hist, grp1, big_p ? c->totals : nullptr,
-                         0u, 32u, nt, n_groups, f.n_padded, c->records, nt, 0, nullptr);
+                         0u, 32u, nt, n_groups, f.n_padded, c->records, nt, 0, nullptr, 0, nullptr, nullptr, 0, nullptr, false, ballot);
             rec_sorted = c->rec_b;
             stage = c->rec_a;
             bofs = c->qbofs2;
@@ -631,7 +632,7 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
         uint32_t* skey = c->out_key ? c->keys_a : nullptr;
         prof_mark(c, "k3_local");
         cmk3_local(st, c->d_frame, state, c->h_state_dev, rec_sorted, c->tile_state, grp_cnt, stage, skey, c->vals_a, false, 0u,
-                   0u, spl, bofs, nb, spl_next);
+                   0u, spl, bofs, nb, spl_next, ballot);
         c->wrote_spl = true;
         prof_mark(c, "k3_compact");
         cmk3_compact(st, state, state_next, c->h_state_dev, c->tile_state, grp_cnt, stage, skey, c->vals_a, c->out, c->out_key,
@@ -700,10 +701,10 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
                      // (fewer than a sixteenth of the points survived the last frame's crop: eight tiles per workgroup)
                      // (... and few enough that a wave's share of a tile is one load: k2_scatter_sparse takes a chunk of more
                      // than 64 records through a loop — at 20 % survivors, the live node's ROI, 40 us against 7)
-                     pack && pass == 0 && !c->debug_misrank && 16ull * c->last_n_merged < c->n_in);
+                     pack && pass == 0 && !c->debug_misrank && 16ull * c->last_n_merged < c->n_in, !c->lds_rank);
     }
     const void* rec_sorted = ((n_global - 1) & 1u) ? c->rec_b : c->rec_a;
-    c->last_k3 = c->finish_mode != 2;
+    c->last_k3 = c->finish_mode != 2 || !c->lds_rank;     // (k2_local ranks by returning LDS adds only)
     if (c->last_k3) {
         // k3_local stages every tile's centroids in the record buffer the last pass read from (dead by now), at the
         // tile's own place; k3_compact moves them to `out`. Cells and counts (CM_FLAG_OCCUPANCY) ride in the general
@@ -721,7 +722,7 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
         uint32_t* spl_next = mode == 0 ? c->spl[c->spl_cur ^ 1] : nullptr;
         c->wrote_spl = spl_next != nullptr;
         cmk3_local(st, c->d_frame, state, c->h_state_dev, rec_sorted, c->tile_state, grp_cnt, stage, skey, c->vals_a, mode == 1,
-                   low_bits, nt_later * CM_TILE, nullptr, nullptr, 0u, spl_next);
+                   low_bits, nt_later * CM_TILE, nullptr, nullptr, 0u, spl_next, !c->lds_rank);
         prof_mark(c, "k3_compact");
         cmk3_compact(st, state, state_next, c->h_state_dev, c->tile_state, grp_cnt, stage, skey, c->vals_a,
                      mode == 1 ? c->partial : c->out, c->out_key, c->out_cnt, mode == 1, nt_later * CM_TILE);
@@ -844,7 +845,9 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
     c->post_bucket = false;
     c->pre_bucket = false;
     c->last_outl = outl; c->last_gm_o = gm_o; c->last_kb_o = kb_o;
-    bool want_v2 = c->path_mode != 1 && (mode == 0 || mode == 1) && c->lds_rank && (!pre || grid_mode == 1);
+    // (without lane-ordered LDS adds — probe failed, CM_LDS_RANK=0, or a pass found mis-ranked — the bucket kernels rank by
+    // ballots: same results, more instructions; the outlier stage's bucket sort, which builds on k2_local, then stays off)
+    bool want_v2 = c->path_mode != 1 && (mode == 0 || mode == 1) && (!pre || grid_mode == 1);
     if (want_v2 && c->v2_off_frames) { --c->v2_off_frames; want_v2 = false; }
     if (want_v2) {
         int gm = grid_mode;
@@ -896,7 +899,7 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
                 if (!pre) return launch_bucket(c, gm, g, low, nullptr, nullptr, mode, quant);
                 c->post_bucket = true; c->post_g = g; c->post_low = low;
                 // the outlier stage's own sort can use the bucket kernels as well: the crop box fixes its grid too
-                c->pre_bucket = gm_o == 1 && box_grid(p->crop_min, p->crop_max, inv_cell, &kb_o, f.cell_min_b, f.cell_div_b) &&
+                c->pre_bucket = c->lds_rank && gm_o == 1 && box_grid(p->crop_min, p->crop_max, inv_cell, &kb_o, f.cell_min_b, f.cell_div_b) &&
                                 static_cast<uint64_t>(f.cell_div_b[1]) * static_cast<uint64_t>(f.cell_div_b[2]) <= CM_ROW_TABLE_CAP &&
                                 f.cell_div_b[0] < (1 << 24) && f.cell_div_b[1] < (1 << 24) && f.cell_div_b[2] < (1 << 24);
                 f.cell_key_bits = kb_o; f._pad_cell = 0;
@@ -1095,7 +1098,7 @@ int launch_classic(cm_ctx* c, const cm_params* p, int mode, int grid_mode, uint3
 // redoes the frame on the general path).
 bool redo_in_measured_box(cm_ctx* c, const CmFrameState& h0) {
     if (!h0.outside || h0.err || !c->last_predicted || c->last_mode != 0 || c->frame_mask || c->last_outl || c->ground_on ||
-        c->path_mode == 1 || !c->lds_rank || h0.n_valid_k0 == 0 || c->frame.n_padded == 0)
+        c->path_mode == 1 || h0.n_valid_k0 == 0 || c->frame.n_padded == 0)
         return false;
     // Everything that can still say "no" works on copies: the frame's descriptor and the predicted box only change once the
     // redo is certain to be launched (a refusal leaves c->frame as the general path's redo expects it — ADVICE r2).
@@ -1197,8 +1200,9 @@ int wait_frame(cm_ctx* c, cm_result* res) {
                 if (h0.err == CM_DEV_ERR_GRID) c->grid_shrink_off = 64;   // more records than the last frame promised: whole grids for a while
                 if (h0.outside) c->pred_ok = false;
                 // The finish found records out of bucket order: a global pass mis-ranked. Stop trusting lane-ordered LDS adds
-                // on this device (the general path then ranks by ballots, and the bucket path, which needs them, stays off).
-                if (h0.err == CM_DEV_ERR_UNSORTED) { c->lds_rank = false; c->h_state->err = 0; }
+                // on this device: from here on every kernel of the context ranks by ballots (this frame is redone on the
+                // general path; the next ones take the bucket path again, ballot-ranked).
+                if (h0.err == CM_DEV_ERR_UNSORTED) { c->lds_rank = false; c->h_state->err = 0; c->debug_misrank = 0; }   // (the test hook fires once)
                 if (h0.err == CM_DEV_ERR_BUCKET) {
                     if (c->v2_extra_passes < CM_MAX_PASSES) ++c->v2_extra_passes;
                     if (c->v2_good_frames < 8 && c->v2_retry_after < (1u << 20)) c->v2_retry_after *= 2;   // the retry failed at once

@@ -106,6 +106,26 @@ __device__ __forceinline__ float wave_max_f32_l63(float v) {
 #undef CM_DPP_F
 }
 
+// Rank of a record among the records of its wave with the same digit — this instruction's lower lanes and everything the wave
+// ranked before — WITHOUT relying on the order in which the LDS executes the returning adds of one instruction (the default
+// ranking does, after the device probe k_probe_lds_order has found them lane-ordered; this is what a context falls back to when
+// the probe fails, CM_LDS_RANK=0, or the finish finds a pass mis-ranked). `row`: the wave's own counters, two 16-bit counters per
+// word. nbits ballots find the lanes that share my digit; every lane reads its counter, then the lowest lane of each group
+// adds the group's size (an atomic add only because two groups may share a word; LDS operations of one wave execute in order).
+__device__ __forceinline__ uint32_t wave_rank_ballot(uint32_t* __restrict__ row, uint32_t digit, uint32_t nbits, bool has, int lane) {
+    unsigned long long m = __ballot(has);
+    for (uint32_t b = 0; b < nbits; ++b) {
+        const bool bit = (digit >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
+    }
+    const uint32_t sh = (digit & 1u) * 16u;
+    uint32_t old = 0;
+    if (has) old = (row[digit >> 1] >> sh) & 0xFFFFu;
+    if (has && lane == __ffsll(static_cast<long long>(m)) - 1) atomicAdd(&row[digit >> 1], static_cast<uint32_t>(__popcll(m)) << sh);
+    return old + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
+}
+
 // Exclusive scan over the 256 threads of a workgroup. lds: CM_WAVES words. Ends with a barrier.
 __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* lds, uint32_t* total) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;

@@ -58,7 +58,8 @@ void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, const CmTileD
                   uint32_t shift, uint32_t next_shift, uint32_t n_tiles, uint32_t n_groups, uint32_t n_padded,
                   const float* records, uint32_t n_records, int fold, const unsigned char* mask, int use_cell = 0,
                   const void* compact_in = nullptr, const uint32_t* wave_cnt = nullptr, int debug_swap = 0,
-                  uint32_t* tile_kept = nullptr, bool sparse = false);   // sparse: k2_scatter_sparse (first pass over packed survivors)
+                  uint32_t* tile_kept = nullptr, bool sparse = false,    // sparse: k2_scatter_sparse (first pass over packed survivors)
+                  bool ballot = false);                                  // ballot: ranks by ballots, not by returning LDS adds (cm_common.hpp)
 void cmk2_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next, uint32_t* host_state,
                 const void* rec, unsigned long long* tile_state, uint32_t* ticket, void* out, uint32_t* out_key,
                 uint32_t* out_cnt, void* partial_out, uint32_t low_bits, uint32_t n_padded);
@@ -73,7 +74,8 @@ void cmk2_local_sort(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint
 void cmk3_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* host_state, const void* rec, void* tile_info,
                 uint32_t* grp_cnt, void* stage, uint32_t* stage_key, uint32_t* stage_cnt, bool partial, uint32_t low_bits,
                 uint32_t n_slots,                          // n_slots / 2048 workgroups (n_padded, or what the records are expected to need)
-                const uint32_t* spl = nullptr, const uint32_t* bofs = nullptr, uint32_t n_buckets = 0, uint32_t* spl_next = nullptr);
+                const uint32_t* spl = nullptr, const uint32_t* bofs = nullptr, uint32_t n_buckets = 0, uint32_t* spl_next = nullptr,
+                bool ballot = false);
 void cmk3_compact(hipStream_t s, const CmFrameState* st, CmFrameState* st_next, uint32_t* host_state, const void* tile_info,
                   const uint32_t* grp_cnt, const void* stage, const uint32_t* stage_key, const uint32_t* stage_cnt, void* out,
                   uint32_t* out_key, uint32_t* out_cnt, bool partial, uint32_t n_padded, uint32_t n_buckets = 0);
@@ -90,7 +92,8 @@ void cmk4_colscan(hipStream_t s, CmFrameState* st, uint32_t* host_state, uint32_
 void cmk4_scatter(hipStream_t s, const CmFrameDev* fd, const CmTileDev* tiles, CmFrameState* st, const uint16_t* bid,
                   const uint32_t* cnt, const uint32_t* totals, uint32_t* bofs, uint32_t n_buckets, void* rec_out,
                   const float* records, uint32_t n_records, int fold, uint32_t* tile_kept, uint32_t n_tiles,
-                  unsigned char* dig_out);                             // (> CM4_BINS buckets: the high part of every record's bucket number)
+                  unsigned char* dig_out,                              // (> CM4_BINS buckets: the high part of every record's bucket number)
+                  bool ballot = false);
 // two passes: where every bucket starts once the second pass has run (bofs_lo: what cmk4_scatter left; idtot: CM4_MAX_BUCKETS words)
 void cmk4_bucket_starts(hipStream_t s, CmFrameState* st, uint32_t* host_state, const uint32_t* bofs_lo, const unsigned char* dig,
                         uint32_t* idtot, uint32_t* bofs, uint32_t n_buckets, uint32_t cap);

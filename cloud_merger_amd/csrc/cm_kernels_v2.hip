@@ -351,7 +351,7 @@ __device__ __forceinline__ void fold_bounds(float* s_f, CmFrameState* __restrict
 // Ranking: returning LDS adds per wave (cm_kernels.hip k_scatter<*, true>; the path is only
 // selected after the device probe passed).
 // ------------------------------------------------------------------------------------------------
-template <bool FIRST>
+template <bool FIRST, bool BALLOT>
 __global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __restrict__ fd,
                                                            const CmTileDev* __restrict__ tiles,
                                                            CmFrameState* __restrict__ st,
@@ -531,6 +531,13 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __r
     }
     for (uint32_t q = threadIdx.x; q < CM2_WAVES * CM_RADIX / 2; q += CM2_BLOCK) (&whist[0][0])[q] = 0;
     __syncthreads();
+    if (BALLOT) {                                          // (ranking by ballots: cm_common.hpp wave_rank_ballot)
+#pragma unroll
+        for (int r = 0; r < CM2_ITEMS; ++r) {
+            lp[r] |= wave_rank_ballot(whist[w], lp[r] & 0xFFu, 8u, (vmask >> r) & 1u, lane) << 16;
+            asm volatile("" : "+v"(lp[r]));
+        }
+    } else {
     // The returning adds go out one behind the other (a slot without a record adds nothing), the ranks are taken once all
     // are back: under a branch each the wave waited for every single one.
 #pragma unroll
@@ -549,6 +556,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __r
             lp[r] |= ((got[r - r0] >> ((lp[r] & 1u) * 16u)) & 0xFFFFu) << 16;
             asm volatile("" : "+v"(lp[r]));                 // (formed here, not where it is next used: the raw returns would have to stay alive)
         }
+    }
     }
     __syncthreads();
     PH((FIRST ? 0 : 8) + 2);
@@ -645,6 +653,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __r
 // order, ranked by returning LDS adds on counters of its own, written straight from registers (few records: no
 // staging) — without another workgroup barrier. Same positions as k2_scatter<true>, record for record.
 // ------------------------------------------------------------------------------------------------
+template <bool BALLOT>
 __global__ __launch_bounds__(CM2_BLOCK) void k2_scatter_sparse(const CmFrameDev* __restrict__ fd, CmFrameState* __restrict__ st,
                                                                const float4* __restrict__ compact_in,
                                                                const uint32_t* __restrict__ wave_cnt,
@@ -719,9 +728,10 @@ __global__ __launch_bounds__(CM2_BLOCK) void k2_scatter_sparse(const CmFrameDev*
         const uint32_t k = key_of(b, r4);
         const uint32_t dg = (k >> shift) & (CM_RADIX - 1), sh = (dg & 1u) * 16u;
         // (a lane without a record adds nothing, to a word of its own: see k2_scatter)
-        const uint32_t old = atomicAdd(&wcnt[w][has ? dg >> 1 : static_cast<uint32_t>(lane)], (has ? 1u : 0u) << sh);
+        const uint32_t rank = BALLOT ? wave_rank_ballot(wcnt[w], dg, 8u, has, lane)
+                                     : (atomicAdd(&wcnt[w][has ? dg >> 1 : static_cast<uint32_t>(lane)], (has ? 1u : 0u) << sh) >> sh) & 0xFFFFu;
         if (has) {
-            const uint32_t pos = offs[w][dg] + ((old >> sh) & 0xFFFFu);
+            const uint32_t pos = offs[w][dg] + rank;
             rec_out[pos] = r4;
             if (next_shift < 32u) dig_out[pos] = static_cast<unsigned char>((k >> next_shift) & 0xFFu);
         }
@@ -1157,23 +1167,23 @@ void cmk2_scatter(hipStream_t s, bool first, const CmFrameDev* fd, const CmTileD
                   unsigned char* dig_out, const uint32_t* hist, const uint32_t* grp, const uint32_t* totals,
                   uint32_t shift, uint32_t next_shift, uint32_t n_tiles, uint32_t n_groups, uint32_t n_padded,
                   const float* records, uint32_t n_records, int fold, const unsigned char* mask, int use_cell,
-                  const void* compact_in, const uint32_t* wave_cnt, int debug_swap, uint32_t* tile_kept, bool sparse) {
+                  const void* compact_in, const uint32_t* wave_cnt, int debug_swap, uint32_t* tile_kept, bool sparse, bool ballot) {
     const float4* in = reinterpret_cast<const float4*>(rec_in);
     float4* o = reinterpret_cast<float4*>(rec_out);
     if (first && compact_in && sparse) {
-        hipLaunchKernelGGL(k2_scatter_sparse, dim3((n_tiles + CM2_WAVES - 1) / CM2_WAVES), dim3(CM2_BLOCK), 0, s, fd, st,
-                           reinterpret_cast<const float4*>(compact_in), wave_cnt, o, dig_out, hist, grp, totals, shift,
-                           next_shift, n_groups, n_tiles, use_cell, tile_kept);
+#define CM2_SPARSE(BAL) hipLaunchKernelGGL(k2_scatter_sparse<BAL>, dim3((n_tiles + CM2_WAVES - 1) / CM2_WAVES), dim3(CM2_BLOCK), 0, s, fd, st, \
+                                           reinterpret_cast<const float4*>(compact_in), wave_cnt, o, dig_out, hist, grp, totals, shift,       \
+                                           next_shift, n_groups, n_tiles, use_cell, tile_kept)
+        if (ballot) CM2_SPARSE(true); else CM2_SPARSE(false);
+#undef CM2_SPARSE
         return;
     }
-    if (first)
-        hipLaunchKernelGGL(k2_scatter<true>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, in, o, dig_out, hist, grp,
-                           totals, shift, next_shift, n_groups, n_padded, records, n_records, fold, mask, use_cell,
-                           reinterpret_cast<const float4*>(compact_in), wave_cnt, debug_swap, tile_kept);
-    else
-        hipLaunchKernelGGL(k2_scatter<false>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, in, o, dig_out, hist, grp,
-                           totals, shift, next_shift, n_groups, n_padded, records, n_records, fold, mask, use_cell,
-                           reinterpret_cast<const float4*>(compact_in), wave_cnt, debug_swap, tile_kept);
+#define CM2_SCATTER(FIRST, BAL) hipLaunchKernelGGL((k2_scatter<FIRST, BAL>), dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, in, o, dig_out, hist, grp, \
+                                                   totals, shift, next_shift, n_groups, n_padded, records, n_records, fold, mask, use_cell,          \
+                                                   reinterpret_cast<const float4*>(compact_in), wave_cnt, debug_swap, tile_kept)
+    if (first) { if (ballot) CM2_SCATTER(true, true); else CM2_SCATTER(true, false); }
+    else { if (ballot) CM2_SCATTER(false, true); else CM2_SCATTER(false, false); }
+#undef CM2_SCATTER
 }
 void cmk2_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, CmFrameState* st_next, uint32_t* host_state,
                 const void* rec, unsigned long long* tile_state, uint32_t* ticket, void* out, uint32_t* out_key,

@@ -90,7 +90,7 @@ __device__ unsigned long long g_phase3[4096 * 16];
 // ------------------------------------------------------------------------------------------------
 // k3_local
 // ------------------------------------------------------------------------------------------------
-template <int LT, int LCAP, int LBLOCK, int WPS, bool PARTIAL, bool QUANT>
+template <int LT, int LCAP, int LBLOCK, int WPS, bool PARTIAL, bool QUANT, bool BALLOT>
 __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __restrict__ fd,
                                                       CmFrameState* __restrict__ st,
                                                       uint32_t* __restrict__ host_state,
@@ -281,7 +281,8 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
                 const uint32_t sh = (dg[r] & 1u) * 16u;
                 rk[r] = 0;
                 if (static_cast<uint32_t>(r) >= rounds) break;         // (uniform)
-                if (e < m) rk[r] = (atomicAdd(&whist[w][dg[r] >> 1], 1u << sh) >> sh) & 0xFFFFu;
+                if (BALLOT) rk[r] = wave_rank_ballot(whist[w], dg[r], wp, e < m, lane);        // (cm_common.hpp: no returning adds)
+                else if (e < m) rk[r] = (atomicAdd(&whist[w][dg[r] >> 1], 1u << sh) >> sh) & 0xFFFFu;
             }
             __syncthreads();
             // thread t < words: digits 2t and 2t+1. Totals over the waves, exclusive prefix over the digits (one barrier: the
@@ -679,24 +680,24 @@ extern "C" __attribute__((visibility("default"))) void cm_debug_phases3(unsigned
 
 void cmk3_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* host_state, const void* rec, void* tile_info,
                 uint32_t* grp_cnt, void* stage, uint32_t* stage_key, uint32_t* stage_cnt, bool partial, uint32_t low_bits,
-                uint32_t n_padded, const uint32_t* spl, const uint32_t* bofs, uint32_t n_buckets, uint32_t* spl_next) {
+                uint32_t n_padded, const uint32_t* spl, const uint32_t* bofs, uint32_t n_buckets, uint32_t* spl_next, bool ballot) {
     // 2048-record tiles, room for 4032 (bucket tails of up to 1984 records), 512 threads at no more than 64 registers:
     // 40 912 bytes of LDS — four workgroups per CU, all eight wave slots of every SIMD (44 us at cfg2; with room for 4096 the
     // fourth workgroup does not fit the CU's 160 KiB: 47 us). n_buckets != 0: one workgroup per quantile bucket (cm_kernels_v4.hip).
+    // ballot: the LDS sort ranks by ballots instead of returning adds (cm_common.hpp wave_rank_ballot).
     static_assert(CM4_CAP == 4032, "k4_colscan's capacity check is this kernel's LCAP");
     const dim3 grid(n_buckets ? n_buckets : n_padded / 2048);
-    if (n_buckets)
-        hipLaunchKernelGGL((k3_local<2048, 4032, 512, 8, false, true>), grid, dim3(512), 0, s, fd, st, host_state,
-                           reinterpret_cast<const float4*>(rec), reinterpret_cast<uint2*>(tile_info), grp_cnt,
-                           reinterpret_cast<float4*>(stage), stage_key, stage_cnt, low_bits, spl, bofs, n_buckets, spl_next);
-    else if (partial)
-        hipLaunchKernelGGL((k3_local<2048, 4032, 512, 8, true, false>), grid, dim3(512), 0, s, fd, st, host_state,
-                           reinterpret_cast<const float4*>(rec), reinterpret_cast<uint2*>(tile_info), grp_cnt,
-                           reinterpret_cast<float4*>(stage), nullptr, nullptr, low_bits, nullptr, nullptr, 0u, nullptr);
-    else
-        hipLaunchKernelGGL((k3_local<2048, 4032, 512, 8, false, false>), grid, dim3(512), 0, s, fd, st, host_state,
-                           reinterpret_cast<const float4*>(rec), reinterpret_cast<uint2*>(tile_info), grp_cnt,
-                           reinterpret_cast<float4*>(stage), stage_key, stage_cnt, low_bits, nullptr, nullptr, 0u, spl_next);
+#define CM3_LOCAL(PART, QUANT, BAL, SK, SC, SPL, BOFS, NB, NEXT)                                                                   \
+    hipLaunchKernelGGL((k3_local<2048, 4032, 512, 8, PART, QUANT, BAL>), grid, dim3(512), 0, s, fd, st, host_state,                 \
+                       reinterpret_cast<const float4*>(rec), reinterpret_cast<uint2*>(tile_info), grp_cnt,                          \
+                       reinterpret_cast<float4*>(stage), SK, SC, low_bits, SPL, BOFS, NB, NEXT)
+    if (n_buckets) { if (ballot) CM3_LOCAL(false, true, true, stage_key, stage_cnt, spl, bofs, n_buckets, spl_next);
+                     else CM3_LOCAL(false, true, false, stage_key, stage_cnt, spl, bofs, n_buckets, spl_next); }
+    else if (partial) { if (ballot) CM3_LOCAL(true, false, true, nullptr, nullptr, nullptr, nullptr, 0u, nullptr);
+                        else CM3_LOCAL(true, false, false, nullptr, nullptr, nullptr, nullptr, 0u, nullptr); }
+    else { if (ballot) CM3_LOCAL(false, false, true, stage_key, stage_cnt, nullptr, nullptr, 0u, spl_next);
+           else CM3_LOCAL(false, false, false, stage_key, stage_cnt, nullptr, nullptr, 0u, spl_next); }
+#undef CM3_LOCAL
 }
 
 void cmk3_compact(hipStream_t s, const CmFrameState* st, CmFrameState* st_next, uint32_t* host_state, const void* tile_info,

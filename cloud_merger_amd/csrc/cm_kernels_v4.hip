@@ -357,7 +357,7 @@ __global__ __launch_bounds__(1024) void k4_colscan(CmFrameState* __restrict__ st
 // buckets in ascending address order with same-bucket records side by side, which is what lets the XCD's L2 put the
 // 32-byte runs of neighbouring tiles together (file header). Tiles are dealt to the XCDs in contiguous ranges.
 // ------------------------------------------------------------------------------------------------
-template <bool TWO>
+template <bool TWO, bool BALLOT>
 __global__ __launch_bounds__(CM2_BLOCK, 6) void k4_scatter(const CmFrameDev* __restrict__ fd, const CmTileDev* __restrict__ tiles,
                                                            CmFrameState* __restrict__ st, const uint16_t* __restrict__ bid,
                                                            const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ totals,
@@ -425,6 +425,11 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k4_scatter(const CmFrameDev* __r
     const uint2 trow = *reinterpret_cast<const uint2*>(cnt + cnt_at(tile, 2 * threadIdx.x, gridDim.x));
     const uint4 tot4 = *reinterpret_cast<const uint4*>(totals + 4 * threadIdx.x);
     // (from here on bk[r] = bucket | rank among the wave's records of the bucket << 16)
+    if (BALLOT) {                                          // (ranking by ballots: cm_common.hpp wave_rank_ballot)
+#pragma unroll
+        for (int r = 0; r < CM2_ITEMS; ++r)
+            bk[r] |= wave_rank_ballot(wcnt[w], bk[r] & (CM4_BINS - 1), 11u, (vmask >> r) & 1u, lane) << 16;
+    } else {
 #pragma unroll
     for (int r0 = 0; r0 < CM2_ITEMS; r0 += 4) {
         uint32_t got[4];
@@ -439,6 +444,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k4_scatter(const CmFrameDev* __r
             bk[r] |= ((got[r - r0] >> ((bk[r] & 1u) * 16u)) & 0xFFFFu) << 16;
             asm volatile("" : "+v"(bk[r]));                 // (formed here: the raw returns need not stay alive)
         }
+    }
     }
     __syncthreads();
     // thread t: counter words 2t, 2t+1 = buckets 4t .. 4t+3. Per bucket: prefix over the waves; first sorted position of
@@ -595,13 +601,13 @@ void cmk4_colscan(hipStream_t s, CmFrameState* st, uint32_t* host_state, uint32_
 }
 void cmk4_scatter(hipStream_t s, const CmFrameDev* fd, const CmTileDev* tiles, CmFrameState* st, const uint16_t* bid,
                   const uint32_t* cnt, const uint32_t* totals, uint32_t* bofs, uint32_t n_buckets, void* rec_out,
-                  const float* records, uint32_t n_records, int fold, uint32_t* tile_kept, uint32_t n_tiles, unsigned char* dig_out) {
-    if (n_buckets > CM4_BINS)
-        hipLaunchKernelGGL(k4_scatter<true>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, bid, cnt, totals, bofs, n_buckets,
-                           reinterpret_cast<float4*>(rec_out), records, n_records, fold, tile_kept, dig_out);
-    else
-        hipLaunchKernelGGL(k4_scatter<false>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, bid, cnt, totals, bofs, n_buckets,
-                           reinterpret_cast<float4*>(rec_out), records, n_records, fold, tile_kept, nullptr);
+                  const float* records, uint32_t n_records, int fold, uint32_t* tile_kept, uint32_t n_tiles, unsigned char* dig_out,
+                  bool ballot) {
+#define CM4_SCATTER(TWO, BAL, DIG) hipLaunchKernelGGL((k4_scatter<TWO, BAL>), dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, bid, cnt, totals, \
+                                                      bofs, n_buckets, reinterpret_cast<float4*>(rec_out), records, n_records, fold, tile_kept, DIG)
+    if (n_buckets > CM4_BINS) { if (ballot) CM4_SCATTER(true, true, dig_out); else CM4_SCATTER(true, false, dig_out); }
+    else { if (ballot) CM4_SCATTER(false, true, nullptr); else CM4_SCATTER(false, false, nullptr); }
+#undef CM4_SCATTER
 }
 void cmk4_bucket_starts(hipStream_t s, CmFrameState* st, uint32_t* host_state, const uint32_t* bofs_lo, const unsigned char* dig,
                         uint32_t* idtot, uint32_t* bofs, uint32_t n_buckets, uint32_t cap) {

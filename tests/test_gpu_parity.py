@@ -811,7 +811,7 @@ def test_mis_ranked_global_pass_is_noticed_and_redone(sort_path):
     record to the next. The TEST BUILD of the library (-DCM_TEST_HOOKS: libcloudmerge_hip_testhooks.so; the shipped library
     holds no such code — VERDICT r2 weak 9) with CM_DEBUG_MISRANK=1 makes the last global pass swap two records of tile 0
     on their way out: the frame must come back CM_PATH_REDONE with the oracle's result, and the context stops trusting
-    the LDS ranking (no bucket path afterwards, ballot ranking on the general path). Run in a child process: a process
+    the LDS ranking (every kernel of it ranks by ballots afterwards — the bucket path included: VERDICT r2 item 7a). Run in a child process: a process
     loads one build of the library."""
     import json
     import os
@@ -840,7 +840,8 @@ def test_mis_ranked_global_pass_is_noticed_and_redone(sort_path):
         assert not any(f & (BUCKET | REDONE) for f in flags)       # (general path: the hook has nothing to touch)
     else:
         assert flags[0] & REDONE and not flags[0] & 1, "handed back, LDS ranking dropped"
-        assert not flags[1] & (BUCKET | REDONE | 1), "the bucket path stays off on this context"
+        # (round 3: the context does not fall back to the general path for good — its bucket kernels rank by ballots from here on)
+        assert flags[1] & BUCKET and not flags[1] & (REDONE | 1), "the next frame takes the bucket path again, ballot-ranked"
 
 
 def test_shipped_library_ignores_the_test_hook(sort_path, monkeypatch):

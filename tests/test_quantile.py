@@ -159,3 +159,27 @@ def test_big_frame_takes_two_quantile_passes(monkeypatch):
         # passes and leaves the splitters; from then on two quantile passes)
         assert not seen[0][1] and seen[1][0] == 3 and not seen[1][1], seen
         assert seen[2] == (2, True, False) and seen[3] == (2, True, False), seen
+
+
+@pytest.mark.parametrize("min_pts", [0, 2])
+def test_ballot_ranked_bucket_path(min_pts, monkeypatch):
+    """a device whose LDS-order probe fails (forced here: CM_LDS_RANK=0) does not lose the bucket path — its
+    kernels (k2_scatter, k4_scatter, k3_local's LDS sort) rank by ballots instead of returning LDS adds (cm_common.hpp
+    wave_rank_ballot): same records in the same stable order, hence the same results; CM_PATH_LDS_RANK is clear in path_flags."""
+    monkeypatch.setenv("CM_LDS_RANK", "0")
+    n_per = 150_000
+    with capi.CloudMerger(max_points_total=4 * n_per, max_sensors=4, flags=capi.FLAG_OCCUPANCY) as cm:
+        flags = []
+        for k in range(3):
+            sensors, params = synth.config2_stream(k, n_per_sensor=n_per, min_pts=min_pts)
+            res, rep = frame_against_oracle(cm, sensors, params, 4 * n_per)
+            flags.append(res.path_flags)
+        assert all(f & BUCKET and not f & 1 for f in flags), flags
+        assert flags[1] & QUANTILE and flags[2] & QUANTILE and not any(f & REDONE for f in flags), flags
+    # a crop box that drops most points: the packed / sparse first scatter, ballot-ranked
+    sensors, params = synth.config3(n_per_sensor=300_000, min_pts=min_pts)
+    n = sum(s.n for s in sensors)
+    with capi.CloudMerger(max_points_total=n, max_sensors=len(sensors), flags=capi.FLAG_OCCUPANCY) as cm:
+        for k in range(3):
+            res, rep = frame_against_oracle(cm, sensors, params, n)
+            assert res.path_flags & BUCKET and not res.path_flags & 1
