@@ -460,7 +460,8 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k2_scatter(const CmFrameDev* __r
         }
     } else if (FIRST) {
         const CmTileDev te = tiles[tile];
-        sidx = te.info & 0xFFu;
+        // (the same in every lane; said so, the sensor's matrix and the crop box below are scalar loads, not twenty VGPRs)
+        sidx = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(te.info & 0xFFu)));
         // (non-temporal: this is the last anybody reads of the raw clouds — with a new cloud every frame they would only push
         // the record buffers out of the Infinity Cache: moving stream, one frame alone 0.144 -> 0.139 ms; nothing in flight)
         load_tile_te<CM2_ITEMS, true>(te, fd->s[sidx], w * (64 * CM2_ITEMS) + lane, p);

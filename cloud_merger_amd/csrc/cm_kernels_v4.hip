@@ -391,7 +391,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k4_scatter(const CmFrameDev* __r
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 
     const CmTileDev te = tiles[tile];
-    const uint32_t sidx = te.info & 0xFFu;
+    const uint32_t sidx = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(te.info & 0xFFu)));   // (uniform: scalar loads of the matrix)
     Pt p[CM2_ITEMS];
     load_tile_te<CM2_ITEMS, true>(te, fd->s[sidx], w * (64 * CM2_ITEMS) + lane, p);     // (non-temporal: the last reader of the raw clouds)
     uint32_t bk[CM2_ITEMS];                               // k4_hist left every slot's bucket (0xFFFF: the slot holds no record)

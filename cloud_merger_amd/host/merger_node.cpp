@@ -220,6 +220,8 @@ int CloudMergerNode::spin_once_pipelined(cm_result* res) {
     t_wait = since(t0); t0 = now();
     if (res) *res = r;
     if (st < 0) { set_error(cm_last_error(ctx_)); return st; }
+    if (r.path_flags & CM_PATH_QUANTILE) n_quantile_.fetch_add(1);
+    if (r.path_flags & CM_PATH_REDONE) n_redone_.fetch_add(1);
     {
         cm_frame_stats fs;
         if (cm_get_frame_stats(ctx_, &fs) == CM_OK)
@@ -320,6 +322,8 @@ int CloudMergerNode::spin_once(cm_result* res) {
     if (res) *res = r;
     if (st == CM_NOT_READY) return st;                              // :575 — nothing fused this tick
     if (st < 0) { set_error(cm_last_error(ctx_)); return st; }
+    if (r.path_flags & CM_PATH_QUANTILE) n_quantile_.fetch_add(1);
+    if (r.path_flags & CM_PATH_REDONE) n_redone_.fetch_add(1);
     {
         // flag reset, :151-157 — for exactly the clouds this fuse read: a callback may have delivered the next one since
         cm_frame_stats fs;

@@ -120,6 +120,9 @@ public:
     void flush();
 
     uint64_t frames_published() const { return frames_; }
+    // how the fused frames were computed (cm_result.path_flags): on the one-pass quantile route / handed back and redone
+    uint64_t frames_quantile() const { return n_quantile_; }
+    uint64_t frames_redone() const { return n_redone_; }
     uint64_t clouds_dropped_for_sync() const { return dropped_; }
 
 private:
@@ -132,6 +135,7 @@ private:
     std::string error_;
     void set_error(const std::string& e) { std::lock_guard<std::mutex> lk(err_mu_); error_ = e; }
     std::atomic<uint64_t> frames_{0};
+    std::atomic<uint64_t> n_quantile_{0}, n_redone_{0};
     uint32_t seq_ = 0;
     PointCloud2 out_msg_, side_msg_;               // reused from frame to frame (no 3 MB zero-fill per publish)
     PointCloud2 pipe_msg_[2];                       // pipelined publish: the message being filled by the copy-out, and the one before

@@ -178,10 +178,12 @@ int main(int argc, char** argv) {
         const uint64_t pts_timed = points * static_cast<uint64_t>(repeat > 1 ? repeat - 1 : 1);
         std::printf("{\"rank\": %d, \"world\": %d, \"frames\": %d, \"points_in\": %llu, \"voxels_out\": %llu, "
                     "\"wall_s\": %.6f, \"submit_merge_publish_s\": %.6f, \"frames_per_s\": %.2f, \"points_per_s\": %.3e, "
-                    "\"mode\": \"subscriber threads (%d) + loop thread%s\", \"warmup_frames\": %d}\n",
+                    "\"mode\": \"subscriber threads (%d) + loop thread%s\", \"warmup_frames\": %d, "
+                    "\"quantile_frames\": %llu, \"redone_frames\": %llu}\n",
                     rank, world, timed, static_cast<unsigned long long>(pts_timed), static_cast<unsigned long long>(voxels - voxels_warm),
                     wall, wall, timed / wall, pts_timed / wall, n_sensors, cfg.pipelined_publish ? ", pipelined publish" : "",
-                    static_cast<int>(n_warm));
+                    static_cast<int>(n_warm), static_cast<unsigned long long>(node.frames_quantile()),
+                    static_cast<unsigned long long>(node.frames_redone()));
         return 0;
     }
 
@@ -222,9 +224,10 @@ int main(int argc, char** argv) {
     std::printf("{\"rank\": %d, \"world\": %d, \"frames\": %d, \"points_in\": %llu, \"voxels_out\": %llu, "
                 "\"wall_s\": %.6f, \"submit_merge_publish_s\": %.6f, \"frames_per_s\": %.2f, \"points_per_s\": %.3e, "
                 "\"tick_ms_p50\": %.4f, \"tick_ms_p99\": %.4f, \"slowest_tick\": %d, \"steady_frames_per_s\": %.2f, "
-                "\"mode\": \"one thread: callbacks, fuse, publish%s\"}\n",
+                "\"mode\": \"one thread: callbacks, fuse, publish%s\", \"quantile_frames\": %llu, \"redone_frames\": %llu}\n",
                 rank, world, done, static_cast<unsigned long long>(points), static_cast<unsigned long long>(voxels), wall,
                 t_gpu, done / t_gpu, points / t_gpu, p50, p99, slowest_tick, tick_ms.empty() ? 0.0 : tick_ms.size() / t_steady,
-                cfg.pipelined_publish ? " (pipelined)" : "");
+                cfg.pipelined_publish ? " (pipelined)" : "", static_cast<unsigned long long>(node.frames_quantile()),
+                static_cast<unsigned long long>(node.frames_redone()));
     return 0;
 }

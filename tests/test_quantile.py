@@ -183,3 +183,37 @@ def test_ballot_ranked_bucket_path(min_pts, monkeypatch):
         for k in range(3):
             res, rep = frame_against_oracle(cm, sensors, params, n)
             assert res.path_flags & BUCKET and not res.path_flags & 1
+
+
+def test_what_changes_between_frames():
+    """The splitters belong to a grid and a scene. Between frames on one context: a sensor drops out (fewer records: the
+    splitters still apply), min_points_per_voxel changes (same grid: they apply), the leaf changes (another grid: the fixed-grid
+    passes run and leave new ones), a frame of empty clouds in between (the splitters survive it). Every frame against the oracle."""
+    n_per = 120_000
+    with capi.CloudMerger(max_points_total=4 * n_per, max_sensors=4, flags=capi.FLAG_OCCUPANCY) as cm:
+        def frame(k, sensors_used=4, **over):
+            sensors, params = synth.config2_stream(k, n_per_sensor=n_per, min_pts=2)
+            for name, v in over.items():
+                setattr(params, name, v)
+            for s in range(sensors_used, 4):
+                cm.clear(s)
+            res, rep = frame_against_oracle(cm, sensors[:sensors_used], params, 4 * n_per)
+            needs_lds_rank(res)
+            return res.path_flags
+        f0 = frame(0)
+        f1 = frame(1)
+        f2 = frame(2, sensors_used=3)                              # one sensor silent: three quarters of the records
+        f3 = frame(3, min_points_per_voxel=0)
+        f4 = frame(4, leaf=(0.08, 0.08, 0.08))                     # another grid
+        f5 = frame(5, leaf=(0.08, 0.08, 0.08))
+        assert not f0 & QUANTILE and f1 & QUANTILE, (f0, f1, f2, f3)
+        assert (f2 & QUANTILE) or (f2 & REDONE), f2                # (tried; three quarters of the points in the same buckets: fits)
+        assert (f3 & QUANTILE) or (f3 & REDONE), f3                # (tried; the fourth sensor's points come back: a bucket may overflow)
+        assert not f4 & QUANTILE and f5 & QUANTILE, (f4, f5)
+        # a frame of empty clouds, then the stream goes on
+        empty = [SensorCloud(data=np.zeros(0, dtype=s.data.dtype), n=0, q_xyzw=s.q_xyzw, t_xyz=s.t_xyz) for s in synth.config2_stream(0, n_per_sensor=8)[0]]
+        cm.submit_all(empty)
+        res = cm.merge_voxelize(synth.config2_stream(0, n_per_sensor=8, min_pts=2)[1])
+        assert res.status == capi.EMPTY_INPUT
+        f6 = frame(0, leaf=(0.08, 0.08, 0.08))
+        assert f6 & BUCKET
