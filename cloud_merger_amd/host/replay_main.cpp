@@ -141,16 +141,19 @@ int main(int argc, char** argv) {
                 points += all[i][s].num_points();
             }
         std::atomic<bool> failed{false};
+        // (set once the loop thread has fused its frames: a sensor the gate does not wait for — the reference's top_middle —
+        // may have been a cloud late at some tick, and would otherwise offer its last clouds for ever to a slot nobody empties)
+        std::atomic<bool> loop_done{false};
         const size_t n_play = all.size() * static_cast<size_t>(repeat);
         const size_t n_warm = repeat > 1 ? all.size() : 0;
         auto t0 = std::chrono::steady_clock::now();
         std::vector<std::thread> subs;
         for (int s = 0; s < n_sensors; ++s)
             subs.emplace_back([&, s] {
-                for (size_t j = 0; j < n_play && !failed.load(); ++j) {
+                for (size_t j = 0; j < n_play && !failed.load() && !loop_done.load(); ++j) {
                     const size_t i = j % all.size();
                     bool accepted = false;
-                    while (!accepted && !failed.load()) {
+                    while (!accepted && !failed.load() && !loop_done.load()) {
                         const int st = node.on_cloud(static_cast<size_t>(s), all[i][s], &accepted);
                         if (st != CM_OK) { std::fprintf(stderr, "on_cloud: %s (%s)\n", cm_status_string(st), node.error().c_str()); failed.store(true); }
                         if (!accepted) std::this_thread::yield();
@@ -170,6 +173,7 @@ int main(int argc, char** argv) {
             ++done;
             if (realtime) std::this_thread::sleep_until(t0 + std::chrono::duration<double>(done / rate));
         }
+        loop_done.store(true);
         for (auto& t : subs) t.join();
         if (failed.load()) return 1;
         node.flush();

@@ -13,7 +13,7 @@ python -m cloud_merger_amd.replay_data $SEQ6 --frames 60 --sensors 6 > /dev/null
 make -C cloud_merger_amd/host -s
 R=./cloud_merger_amd/host/bin/cloudmerge_replay
 OUT=gpurun_out/${TAG}_live_node.jsonl; : > $OUT
-run() { echo "# $*" >> $OUT; for rep in 1 2 3; do "$@" >> $OUT; done; }
+run() { echo "# $*" >> $OUT; for rep in 1 2 3; do timeout -k 5 60 "$@" >> $OUT; done; }
 CROP="--crop -15 -5 -0.5 60 5 3"
 run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.1 --min-pts 2 $CROP
 run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.1 --min-pts 2 $CROP --pipeline
