@@ -490,6 +490,11 @@ def main():
             tpath = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_cfg{args.config}{dense}_minpts{args.min_pts}{suffix}.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
+                same_route = ("quantile" in tj.get("path", "")) == bool(res.path_flags & capi.PATH_QUANTILE)
+                if tj.get("source_hash") == src_hash and not same_route:
+                    traffic_src = {"not_this_route": os.path.relpath(tpath, ROOT), "file_path": tj.get("path", "")[:60],
+                                   "note": "the file was measured on the other route of the bucket path (quantile passes vs fixed grid): not quoted"}
+                    break
                 if tj.get("source_hash") != src_hash:
                     traffic_src = {"stale_file": os.path.relpath(tpath, ROOT), "file_source_hash": tj.get("source_hash"),
                                    "this_build": src_hash, "stale_traffic_high": tj["traffic_high"],
