@@ -180,6 +180,8 @@ struct cm_ctx {
     float spl_inv_leaf[3] = {0, 0, 0};
     uint32_t *qcnt = nullptr, *qtot = nullptr, *qbofs = nullptr;  // per-tile bucket counts / prefixes, bucket totals, bucket starts
     uint32_t *qidtot = nullptr, *qbofs2 = nullptr;                // two passes: totals per bucket number, bucket starts behind the second pass
+    uint32_t* qbig = nullptr;                                     // buckets beyond CM4_CAP records: count, then their numbers
+    uint32_t quant_big_arm = 0;          // quantile frames for which the large finish shape is still launched (armed by a hand-back or a listed bucket)
     uint16_t* qbid = nullptr;            // the bucket of every padded slot
     bool last_quant = false;             // the frame in flight runs the quantile passes
     bool wrote_spl = false;              // ... and its finish leaves splitters in spl[spl_cur ^ 1]
@@ -297,7 +299,7 @@ void free_all(cm_ctx* c) {
     F(c->keys_a); F(c->keys_b); F(c->vals_a); F(c->vals_b); F(c->hist); F(c->totals);
     F(c->seg_counts); F(c->seg_tile_counts); F(c->seg_groups); F(c->grp); F(c->partials); F(c->out_key); F(c->out_cnt); F(c->merged_total); F(c->out); F(c->merged); F(c->partial); F(c->table_entries); F(c->mask); F(c->sorted_pts); F(c->rows); F(c->d_state_o);
     F(c->stage32); F(c->out32); F(c->rec_a); F(c->rec_b); F(c->dig); F(c->tile_state); F(c->wave_cnt); F(c->records);
-    F(c->spl[0]); F(c->spl[1]); F(c->qcnt); F(c->qtot); F(c->qbofs); F(c->qbid); F(c->qidtot); F(c->qbofs2);
+    F(c->spl[0]); F(c->spl[1]); F(c->qcnt); F(c->qtot); F(c->qbofs); F(c->qbid); F(c->qidtot); F(c->qbofs2); F(c->qbig);
     F(c->out_other); F(c->out32_other);
     if (c->pub_stream) (void)hipStreamDestroy(c->pub_stream);
     for (auto e : c->ev_pub) if (e) (void)hipEventDestroy(e);
@@ -548,6 +550,7 @@ int bucket_buffers(cm_ctx* c) {
     if (!c->qbofs) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->qbofs), (CM4_BINS + 4) * 4));
     if (!c->qidtot) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->qidtot), CM4_MAX_BUCKETS * 4));
     if (!c->qbofs2) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->qbofs2), (CM4_MAX_BUCKETS + 4) * 4));
+    if (!c->qbig) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->qbig), (CM4_MAX_BIG + 4) * 4));
     return CM_OK;
 }
 
@@ -602,14 +605,20 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
         uint32_t* grp1 = c->grp + 2 * gstride;           // the second pass's group totals (k2_hist accumulates: cleared by k4_hist)
         prof_mark(c, "k4_hist");
         cmk4_hist(st, f, c->d_frame, c->d_tiles, do_setup_q, state, spl, c->qcnt, c->qbid, c->tile_state, f.n_padded / 1024 + 2, c->records,
-                  grid_mode, predicted ? 1 : 0, nt, nb, two ? grp1 : nullptr, two ? gw : 0u);
+                  grid_mode, predicted ? 1 : 0, nt, nb, two ? grp1 : nullptr, two ? gw : 0u, two ? nullptr : c->qbig);
         prof_mark(c, "k4_colscan");
         // (one pass: a bin is a bucket and must fit the finish; two: a bin holds the buckets of up to four high parts)
-        cmk4_colscan(st, state, c->h_state_dev, c->qcnt, c->qtot, nt, two ? 0xFFFFu : CM4_CAP);
+        // The large finish shape (buckets of up to CM4_CAP_BIG records, one workgroup per CU) costs a launch of its own — 6 us on a
+        // frame alone even when it has nothing to do — so it is only armed for 16 frames behind a hand-back or a frame that used
+        // it; unarmed, any bucket beyond the usual shape's capacity hands the frame back (and arms it).
+        const bool big_armed = !two && c->quant_big_arm > 0;
+        if (c->quant_big_arm) --c->quant_big_arm;
+        cmk4_colscan(st, state, c->h_state_dev, c->qcnt, c->qtot, nt, two ? 0xFFFFu : CM4_CAP, two ? 0xFFFFu : (big_armed ? CM4_CAP_BIG : CM4_CAP),
+                     two ? nullptr : c->qbig);
         prof_mark(c, "k4_scatter");
         const bool ballot = !c->lds_rank;                // ranks by ballots where the returning LDS adds are not (known to be) lane-ordered
         cmk4_scatter(st, c->d_frame, c->d_tiles, state, c->qbid, c->qcnt, c->qtot, c->qbofs, nb, c->rec_a, c->records, nt,
-                     predicted ? 1 : 0, c->d_tile_kept, nt, two ? c->dig : nullptr, ballot);
+                     predicted ? 1 : 0, c->d_tile_kept, nt, two ? c->dig : nullptr, ballot, two ? nullptr : c->qbig);
         const void* rec_sorted = c->rec_a;
         void* stage = c->rec_b;
         const uint32_t* bofs = c->qbofs;
@@ -633,6 +642,12 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
         prof_mark(c, "k3_local");
         cmk3_local(st, c->d_frame, state, c->h_state_dev, rec_sorted, c->tile_state, grp_cnt, stage, skey, c->vals_a, false, 0u,
                    0u, spl, bofs, nb, spl_next, ballot);
+        if (big_armed) {
+            // the few buckets that grew beyond what the usual finish workgroup holds (k4_colscan listed them): the large shape
+            prof_mark(c, "k3_local(big)");
+            cmk3_local_big(st, c->d_frame, state, c->h_state_dev, rec_sorted, c->tile_state, grp_cnt, stage, skey, c->vals_a, spl, bofs, nb,
+                           spl_next, c->qbig, ballot);
+        }
         c->wrote_spl = true;
         prof_mark(c, "k3_compact");
         cmk3_compact(st, state, state_next, c->h_state_dev, c->tile_state, grp_cnt, stage, skey, c->vals_a, c->out, c->out_key,
@@ -1180,6 +1195,7 @@ int wait_frame(cm_ctx* c, cm_result* res) {
                 // moves its points to other buckets).
                 c->quant_hist = ((c->quant_hist << 1) | 1u) & 0xFFu;
                 c->quant_good = 0;
+                c->quant_big_arm = 16;                     // (the next frames may have buckets of two to four times the usual size: the large shape takes them)
                 if (__builtin_popcount(c->quant_hist) >= 3) {
                     c->quant_off_frames = c->quant_rest;
                     if (c->quant_rest < 128) c->quant_rest *= 2;
@@ -1310,6 +1326,7 @@ int wait_frame(cm_ctx* c, cm_result* res) {
             std::memcpy(c->spl_min_b, c->frame.box_min_b, sizeof c->spl_min_b);
             std::memcpy(c->spl_div_b, c->frame.box_div_b, sizeof c->spl_div_b);
             std::memcpy(c->spl_inv_leaf, c->frame.inv_leaf, sizeof c->spl_inv_leaf);
+            if (c->last_quant && h.quant_big) c->quant_big_arm = 16;     // (still needed: stays armed)
             if (c->last_quant && !redone) {
                 c->quant_hist = (c->quant_hist << 1) & 0xFFu;
                 if (++c->quant_good >= 16) c->quant_rest = 8;

@@ -39,7 +39,9 @@
 #define CM4_MAX_BUCKETS 8192  // buckets of a frame: above CM4_BINS the wide pass scatters by the low eleven bits of the bucket number
                               // and a second, narrow pass by the high ones (frames of up to 15 M records)
 #define CM4_TARGET 1920u
-#define CM4_CAP 4032u
+#define CM4_CAP 4032u          // records a finish workgroup of the usual shape holds (k3_local: 512 threads, four per CU)
+#define CM4_CAP_BIG 8064u      // ... and of the large shape (1024 threads, one per CU) that takes the few buckets beyond that
+#define CM4_MAX_BIG 64u        // at most this many such buckets per frame (more: the frame is handed back); the large launch has this many workgroups
 #define CM4_MAX_AVG 2600u     // the host takes the path only while records / buckets stays below this
 #define CM4_MAX_TILES 4096u   // ... and the frame has at most this many 4096-slot tiles (k4_colscan's register tile)
 // Buckets the NEXT frame uses when this one sorted n records (the finish writes that many splitters; the host sizes the grids).
@@ -139,7 +141,8 @@ struct CmFrameState {
     uint32_t outside;         // bucket path: a point fell outside the predicted box (frame must be redone)
     uint32_t quant_abort;     // quantile passes (cm_kernels_v4.hip): a bucket beyond the finish's capacity — every later kernel leaves
     uint32_t spl_incomplete;  // the finish could not leave every quantile (a voxel reached beyond what a tile holds in LDS): no splitters
-    uint32_t _unused[3];
+    uint32_t quant_big;       // quantile passes: buckets this frame handed to the large finish shape (k4_colscan's list)
+    uint32_t _unused[2];
     uint32_t n_valid_k0;      // valid points counted by the min/max pass
     int32_t status;           // cm_status of the frame (0 OK, 1 EMPTY, 2 OVERFLOW)
     int32_t min_b[3], max_b[3], div_b[3];

@@ -102,7 +102,12 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
                                                       uint32_t* __restrict__ stage_cnt,
                                                       uint32_t low_bits,
                                                       const uint32_t* __restrict__ spl, const uint32_t* __restrict__ bofs,
-                                                      uint32_t n_buckets, uint32_t* __restrict__ spl_next) {
+                                                      uint32_t n_buckets, uint32_t* __restrict__ spl_next,
+                                                      const uint32_t* __restrict__ big_list) {
+    // big_list (QUANT): word 0 = how many buckets hold more than CM4_CAP records, then their numbers (k4_colscan). The usual
+    // launch (big_list == nullptr) leaves those alone; a second launch of the LARGE shape (1024 threads, room for CM4_CAP_BIG
+    // records) takes them, workgroup i the i-th of the list: a bucket that doubled or tripled since the last frame costs a
+    // slower workgroup, not a handed-back frame.
     // QUANT (cm_kernels_v4.hip): the records are grouped by quantile bucket — workgroup t takes bucket t, records
     // [bofs[t], bofs[t+1]) with indices in [spl[t], spl[t+1]): no bucket boundaries to look for, no tail to follow.
     // spl_next: where the next frame's splitters go (every tile writes the quantiles that fall into its sorted range).
@@ -116,6 +121,7 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
     __shared__ uint32_t s_a, s_keyprev, s_bad, s_njobs;
     Job3* jobs = reinterpret_cast<Job3*>(&whist[0][0]);         // (the counters are dead once the sort is over: 512 jobs fit)
 
+    if (QUANT && big_list && blockIdx.x >= big_list[0]) return;        // (the large shape's launch: usually nothing to do — leave at once)
     PH3_START();
     // (values that are the same in every lane are put into scalar registers by hand — the compiler cannot tell for what
     // comes out of LDS or global memory — so that the loops below branch and count on the scalar unit)
@@ -125,7 +131,12 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
     if (QUANT && st->quant_abort) return;
     const uint32_t n = SCAL(st->n_valid);
     const uint32_t n_lt = QUANT ? n_buckets : (n + LT - 1) / LT;
-    const uint32_t tile = blockIdx.x;
+    uint32_t tile_ = blockIdx.x;
+    if (QUANT && big_list) {
+        if (tile_ >= SCAL(big_list[0])) return;
+        tile_ = SCAL(big_list[1 + tile_]);
+    }
+    const uint32_t tile = tile_;
     if (tile >= n_lt) return;
     const BoxGrid b = box_grid_of(fd);
     const uint32_t L = QUANT ? 1u : low_bits;                    // (QUANT: only "there is something left to sort")
@@ -135,6 +146,7 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
     const uint32_t base = QUANT ? SCAL(bofs[tile]) : tile * LT;
     const uint32_t q_end = QUANT ? SCAL(bofs[tile + 1]) : 0u;
     const bool q_big = QUANT && (q_end - base) > static_cast<uint32_t>(LCAP);
+    if (QUANT && q_big && !big_list && (q_end - base) <= CM4_CAP_BIG) return;     // (the large shape's launch takes this bucket)
     const uint32_t nom = QUANT ? (q_big ? 0u : q_end - base) : min(static_cast<uint32_t>(LT), n - base);
     const uint32_t q_lo = QUANT ? SCAL(spl[tile]) : 0u;
     const uint32_t q_hi = QUANT ? min(SCAL(spl[tile + 1]), fd->box_key_bits < 32u ? (1u << fd->box_key_bits) : 0xFFFFFFFFu) : 0u;
@@ -690,7 +702,7 @@ void cmk3_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t*
 #define CM3_LOCAL(PART, QUANT, BAL, SK, SC, SPL, BOFS, NB, NEXT)                                                                   \
     hipLaunchKernelGGL((k3_local<2048, 4032, 512, 8, PART, QUANT, BAL>), grid, dim3(512), 0, s, fd, st, host_state,                 \
                        reinterpret_cast<const float4*>(rec), reinterpret_cast<uint2*>(tile_info), grp_cnt,                          \
-                       reinterpret_cast<float4*>(stage), SK, SC, low_bits, SPL, BOFS, NB, NEXT)
+                       reinterpret_cast<float4*>(stage), SK, SC, low_bits, SPL, BOFS, NB, NEXT, nullptr)
     if (n_buckets) { if (ballot) CM3_LOCAL(false, true, true, stage_key, stage_cnt, spl, bofs, n_buckets, spl_next);
                      else CM3_LOCAL(false, true, false, stage_key, stage_cnt, spl, bofs, n_buckets, spl_next); }
     else if (partial) { if (ballot) CM3_LOCAL(true, false, true, nullptr, nullptr, nullptr, nullptr, 0u, nullptr);
@@ -698,6 +710,17 @@ void cmk3_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t*
     else { if (ballot) CM3_LOCAL(false, false, true, stage_key, stage_cnt, nullptr, nullptr, 0u, spl_next);
            else CM3_LOCAL(false, false, false, stage_key, stage_cnt, nullptr, nullptr, 0u, spl_next); }
 #undef CM3_LOCAL
+}
+
+// The buckets of a quantile frame that hold more than CM4_CAP records (big_list: k4_colscan), one workgroup of the large shape each.
+void cmk3_local_big(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* host_state, const void* rec, void* tile_info,
+                    uint32_t* grp_cnt, void* stage, uint32_t* stage_key, uint32_t* stage_cnt, const uint32_t* spl, const uint32_t* bofs,
+                    uint32_t n_buckets, uint32_t* spl_next, const uint32_t* big_list, bool ballot) {
+#define CM3_BIG(BAL) hipLaunchKernelGGL((k3_local<4096, CM4_CAP_BIG, 1024, 4, false, true, BAL>), dim3(CM4_MAX_BIG), dim3(1024), 0, s, fd, st,   \
+                                        host_state, reinterpret_cast<const float4*>(rec), reinterpret_cast<uint2*>(tile_info), grp_cnt,         \
+                                        reinterpret_cast<float4*>(stage), stage_key, stage_cnt, 0u, spl, bofs, n_buckets, spl_next, big_list)
+    if (ballot) CM3_BIG(true); else CM3_BIG(false);
+#undef CM3_BIG
 }
 
 void cmk3_compact(hipStream_t s, const CmFrameState* st, CmFrameState* st_next, uint32_t* host_state, const void* tile_info,

@@ -146,7 +146,8 @@ __global__ __launch_bounds__(CM2_BLOCK) void k4_hist(const CmFrameDev fv, CmFram
                                                      uint32_t* __restrict__ cnt, uint16_t* __restrict__ bid,
                                                      unsigned long long* __restrict__ tile_state, uint32_t n_tile_state,
                                                      float* __restrict__ records, int grid_mode, int check_box,
-                                                     uint32_t* __restrict__ grp_clear, uint32_t n_grp_clear, uint32_t n_passes) {
+                                                     uint32_t* __restrict__ grp_clear, uint32_t n_grp_clear, uint32_t n_passes,
+                                                     uint32_t* __restrict__ big_list) {
     __shared__ uint32_t spl[1 << LEVELS];
     __shared__ uint32_t lh[CM4_BINS / 2];
     __shared__ float s_mm[CM2_WAVES][6];
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(CM2_BLOCK) void k4_hist(const CmFrameDev fv, CmFram
         }
         st->key_bits = fd->box_key_bits;
         st->n_passes = n_passes;
+        if (big_list) big_list[0] = 0u;                    // (k4_colscan's list of buckets for the large finish shape)
     }
     const BoxGrid b = box_grid_of(fd);
     const bool predicted = check_box != 0;
@@ -302,7 +304,10 @@ static_assert(32 * 128 >= CM4_MAX_TILES, "k4_colscan's register tile covers the 
 template <int CM4_SCAN_TPC>
 __global__ __launch_bounds__(1024) void k4_colscan(CmFrameState* __restrict__ st, uint32_t* __restrict__ host_state,
                                                    uint32_t* __restrict__ cnt, uint32_t* __restrict__ totals,
-                                                   uint32_t n_tiles, uint32_t cap) {
+                                                   uint32_t n_tiles, uint32_t cap, uint32_t cap_big, uint32_t* __restrict__ big_list) {
+    // cap: what a finish workgroup of the usual shape holds; a bucket beyond it (up to cap_big) goes on big_list — word 0 the
+    // count (zeroed by k4_hist), then the bucket numbers — for the large shape's launch; beyond cap_big, or more than
+    // CM4_MAX_BIG of them, the frame is handed back. (Two passes: cap == cap_big == 0xFFFF, no list: k4_idscan decides.)
     __shared__ uint32_t s_lo[16][8], s_hi[16][8];
     if (st->status != CM_DEV_OK || st->outside) return;
     const uint32_t j = threadIdx.x & 7u, c = threadIdx.x >> 3;
@@ -342,7 +347,18 @@ __global__ __launch_bounds__(1024) void k4_colscan(CmFrameState* __restrict__ st
     if (c == 127u) {
         const uint32_t tlo = plo + lo, thi = phi + hi;
         totals[2 * word] = tlo; totals[2 * word + 1] = thi;
-        if (tlo > cap || thi > cap) {                      // a bucket the finish cannot hold: the frame goes back
+        bool bad = tlo > cap_big || thi > cap_big;
+        if (big_list) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t tv = h ? thi : tlo;
+                if (tv > cap && tv <= cap_big) {
+                    const uint32_t at = atomicAdd(&big_list[0], 1u);
+                    if (at < CM4_MAX_BIG) big_list[1 + at] = 2 * word + h; else bad = true;
+                }
+            }
+        }
+        if (bad) {                                         // a bucket no finish workgroup can hold: the frame goes back
             st->quant_abort = 1u;
             host_state[offsetof(CmFrameState, err) / 4] = CM_DEV_ERR_QUANT;
         }
@@ -364,7 +380,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k4_scatter(const CmFrameDev* __r
                                                            uint32_t* __restrict__ bofs, uint32_t n_buckets,
                                                            float4* __restrict__ rec_out, const float* __restrict__ records,
                                                            uint32_t n_records, int fold, uint32_t* __restrict__ tile_kept,
-                                                           unsigned char* __restrict__ dig_out) {
+                                                           unsigned char* __restrict__ dig_out, const uint32_t* __restrict__ big_list) {
     // TWO: the bucket numbers have up to thirteen bits; this pass scatters by the low eleven and leaves the high ones as a
     // byte beside every record (dig_out), for the second pass (k2_hist + k2_scatter<false>: cm_kernels_v2.hip).
     constexpr int HW = CM4_BINS / 2;                      // counter words per wave
@@ -477,7 +493,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k4_scatter(const CmFrameDev* __r
             r0 += cwq.x & 0xFFFFu; r1 += cwq.x >> 16; r2 += cwq.y & 0xFFFFu; r3 += cwq.y >> 16;
         }
     }
-    if (tile == 0 && threadIdx.x == 0) { st->n_valid = n_total; bofs[CM4_BINS] = n_total; }
+    if (tile == 0 && threadIdx.x == 0) { st->n_valid = n_total; bofs[CM4_BINS] = n_total; st->quant_big = big_list ? big_list[0] : 0u; }
     if (tile_kept && threadIdx.x == 0) tile_kept[tile] = tile_valid;
     __syncthreads();
     // (now bk[r] = bucket | sorted position in the tile << 16; a slot without a record: position 0xFFFF, beyond every round)
@@ -583,28 +599,29 @@ __global__ __launch_bounds__(1024) void k4_idscan(CmFrameState* __restrict__ st,
 
 void cmk4_hist(hipStream_t s, const CmFrameDev& f, CmFrameDev* fd, CmTileDev* tiles, bool do_setup, CmFrameState* st,
                const uint32_t* spl, uint32_t* cnt, uint16_t* bid, unsigned long long* tile_state, uint32_t n_tile_state, float* records,
-               int grid_mode, int check_box, uint32_t n_tiles, uint32_t n_buckets, uint32_t* grp_clear, uint32_t n_grp_clear) {
+               int grid_mode, int check_box, uint32_t n_tiles, uint32_t n_buckets, uint32_t* grp_clear, uint32_t n_grp_clear,
+               uint32_t* big_list) {
     const uint32_t np = n_buckets > CM4_BINS ? 2u : 1u;
 #define CM4_HIST(L) hipLaunchKernelGGL(k4_hist<L>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, f, fd, tiles, do_setup ? 1 : 0, st, spl, cnt, bid, \
-                                       tile_state, n_tile_state, records, grid_mode, check_box, grp_clear, n_grp_clear, np)
+                                       tile_state, n_tile_state, records, grid_mode, check_box, grp_clear, n_grp_clear, np, big_list)
     if (n_buckets <= 2048) CM4_HIST(11);
     else if (n_buckets <= 4096) CM4_HIST(12);
     else CM4_HIST(13);
 #undef CM4_HIST
 }
 void cmk4_colscan(hipStream_t s, CmFrameState* st, uint32_t* host_state, uint32_t* cnt, uint32_t* totals, uint32_t n_tiles,
-                  uint32_t cap) {
+                  uint32_t cap, uint32_t cap_big, uint32_t* big_list) {
     if (n_tiles <= 12 * 128)
-        hipLaunchKernelGGL(k4_colscan<12>, dim3(CM4_BINS / 16), dim3(1024), 0, s, st, host_state, cnt, totals, n_tiles, cap);
+        hipLaunchKernelGGL(k4_colscan<12>, dim3(CM4_BINS / 16), dim3(1024), 0, s, st, host_state, cnt, totals, n_tiles, cap, cap_big, big_list);
     else
-        hipLaunchKernelGGL(k4_colscan<32>, dim3(CM4_BINS / 16), dim3(1024), 0, s, st, host_state, cnt, totals, n_tiles, cap);
+        hipLaunchKernelGGL(k4_colscan<32>, dim3(CM4_BINS / 16), dim3(1024), 0, s, st, host_state, cnt, totals, n_tiles, cap, cap_big, big_list);
 }
 void cmk4_scatter(hipStream_t s, const CmFrameDev* fd, const CmTileDev* tiles, CmFrameState* st, const uint16_t* bid,
                   const uint32_t* cnt, const uint32_t* totals, uint32_t* bofs, uint32_t n_buckets, void* rec_out,
                   const float* records, uint32_t n_records, int fold, uint32_t* tile_kept, uint32_t n_tiles, unsigned char* dig_out,
-                  bool ballot) {
+                  bool ballot, const uint32_t* big_list) {
 #define CM4_SCATTER(TWO, BAL, DIG) hipLaunchKernelGGL((k4_scatter<TWO, BAL>), dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, bid, cnt, totals, \
-                                                      bofs, n_buckets, reinterpret_cast<float4*>(rec_out), records, n_records, fold, tile_kept, DIG)
+                                                      bofs, n_buckets, reinterpret_cast<float4*>(rec_out), records, n_records, fold, tile_kept, DIG, big_list)
     if (n_buckets > CM4_BINS) { if (ballot) CM4_SCATTER(true, true, dig_out); else CM4_SCATTER(true, false, dig_out); }
     else { if (ballot) CM4_SCATTER(false, true, nullptr); else CM4_SCATTER(false, false, nullptr); }
 #undef CM4_SCATTER

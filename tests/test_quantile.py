@@ -75,18 +75,21 @@ def test_full_size_stream():
     """cfg2 itself: 4 x 1 M points, 5 cm, min 2 points per voxel — 2048 buckets of about 1950 records. Six consecutive
     frames of the moving stream on ONE context (bench.py deals them to three): every frame equals the oracle; the poses
     jitter by a couple of milliradians from frame to frame, and one of these transitions (4 -> 5) tilts the ground layer far
-    enough across the 5 cm voxel layers — the index is z-major — that a bucket outgrows the finish: that frame is handed
-    back and redone with the fixed-grid passes (CM_PATH_REDONE), the others take the one quantile pass."""
+    enough across the 5 cm voxel layers — the index is z-major — that a bucket outgrows the finish's usual workgroup: that
+    frame is handed back and redone with the fixed-grid passes (CM_PATH_REDONE), the others take the one quantile pass."""
     with capi.CloudMerger(max_points_total=4_000_000, max_sensors=4, flags=capi.FLAG_OCCUPANCY) as cm:
         flags = []
-        for k in range(6):
-            sensors, params = synth.config2_stream(k, min_pts=2)
+        for k in range(12):
+            sensors, params = synth.config2_stream(k % 6, min_pts=2)
             res, rep = frame_against_oracle(cm, sensors, params, 4_000_000)
             needs_lds_rank(res)
             flags.append(res.path_flags)
         assert not flags[0] & QUANTILE and all(f & QUANTILE for f in flags[1:3]) and not any(f & REDONE for f in flags[:3]), flags
-        assert sum(1 for f in flags[1:] if f & QUANTILE) >= 3, flags
         assert all((f & QUANTILE) or (f & REDONE) for f in flags[1:]), flags    # every later frame tried the quantile pass
+        # A hand-back arms the large finish shape (1024 threads, room for 8064 records) for the next frames: the second time
+        # round, the same transition is a few slower workgroups, not a handed-back frame.
+        if any(f & REDONE for f in flags[1:6]):
+            assert all(f & QUANTILE and not f & REDONE for f in flags[6:]), flags
 
 
 def test_changed_scene_is_handed_back_and_redone():
