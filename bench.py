@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--stream-frames", type=int, default=6, help="distinct frames of the moving stream (6 x 64 MB of input > 256 MiB)")
     ap.add_argument("--jump-every", type=int, default=64, help="every this many frames one reaches 30 %% further out (0: never)")
     ap.add_argument("--static", action="store_true", help="the round-1 loop: one frame resubmitted every step")
+    ap.add_argument("--moving", action="store_true", help="--config 3 --dense: a stream of --stream-frames fresh draws of the scene instead of one frame resubmitted")
     ap.add_argument("--source-hash", action="store_true", help="print the hash of the kernel sources and exit (scripts/pmc_traffic.sh)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffer (PCIe-inclusive) runs")
     ap.add_argument("--dense", action="store_true", help="config 3: points drawn inside the ROI (the sort-stress variant); config 5: "
@@ -260,6 +261,10 @@ def main():
                     "cfg3: 8 x 2M XYZI float32 points, yaw-only SE(3), 2 cm voxel, reference ROI crop")
         sensors0, params = gen(min_pts=args.min_pts)
         frames, wide, moving, K = [sensors0], None, False, 1
+        if args.dense and args.moving:
+            K = max(2, args.stream_frames)
+            frames += [synth.config3_dense(min_pts=args.min_pts, draw=k + 97 * rank)[0] for k in range(1, K)]
+            moving = True
     if args.outlier_radius > 0:
         params.outlier_radius, params.outlier_min_neighbors = args.outlier_radius, 1
         workload += f" + radius outlier removal r={args.outlier_radius} m, min 1 neighbour"
@@ -368,7 +373,9 @@ def main():
         "config": {"workload": workload, "points_per_frame": n_in, "voxels_out": n_out,
                    "min_points_per_voxel": args.min_pts, "sharding": f"frame-sharded x{world}, no collective",
                    "inputs": "resident in HBM (16-byte XYZI records)",
-                   "stream": (f"moving: {K} distinct frames per rank ({K * n_in * 16 >> 20} MiB of input, more than the 256 MiB "
+                   "stream": (f"moving: {K} fresh draws of the scene per rank in turn ({K * n_in * 16 >> 20} MiB of input); a context "
+                              f"sees every {inflight}th frame" if (moving and args.config != 2) else
+                              f"moving: {K} distinct frames per rank ({K * n_in * 16 >> 20} MiB of input, more than the 256 MiB "
                               f"Infinity Cache), poses and bounds jittered from frame to frame; "
                               + (f"{stats['jumped']} of the {args.steps} timed frames reached 30 % further out than the box predicted from "
                                  f"their predecessors (every {args.jump_every}th frame of the stream does)" if stats["jumped"] else

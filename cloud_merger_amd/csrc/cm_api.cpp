@@ -171,6 +171,7 @@ struct cm_ctx {
     bool pub_pending[2] = {false, false};
 
     // quantile passes (cm_kernels_v4.hip): one global pass into buckets cut at the last frame's quantiles
+    bool quant_sub = true;               // CM_QUANT_SUB=0: frames above 2048 buckets take the fixed-grid passes (or CM_QUANT2's two)
     int quant_mode = 0;                  // CM_QUANT: 0 auto, 1 never; 2 (CM_QUANT2=1): auto, and two passes for frames above 2048 buckets
     uint32_t* spl[2] = {nullptr, nullptr};   // splitters: a frame reads spl[spl_cur]; its finish writes spl[spl_cur ^ 1]
     int spl_cur = 0;
@@ -596,7 +597,11 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
         c->frame_mask = nullptr;
         const uint32_t nt = f.n_tiles;
         const uint32_t nb = cm_quant_buckets(c->spl_n);
-        const bool two = nb > CM4_BINS;                  // more buckets than the wide pass has bins: a second, narrow pass
+        // more buckets than the pass has bins: 2^sub neighbouring buckets share a bin and the finish picks its records out of
+        // it (k3_local<SUB>) — or, CM_QUANT2=1, a second, narrow pass
+        const bool two = nb > CM4_BINS && c->quant_mode == 2;
+        const uint32_t sub = (nb > CM4_BINS && !two) ? cm_quant_sub_shift(nb) : 0u;
+        const uint32_t nbins = sub ? (nb + (1u << sub) - 1u) >> sub : nb;
         const uint32_t* spl = c->spl[c->spl_cur];
         uint32_t* spl_next = c->spl[c->spl_cur ^ 1];
         const uint32_t n_groups = (nt + CM_GROUP - 1) / CM_GROUP;
@@ -605,20 +610,23 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
         uint32_t* grp1 = c->grp + 2 * gstride;           // the second pass's group totals (k2_hist accumulates: cleared by k4_hist)
         prof_mark(c, "k4_hist");
         cmk4_hist(st, f, c->d_frame, c->d_tiles, do_setup_q, state, spl, c->qcnt, c->qbid, c->tile_state, f.n_padded / 1024 + 2, c->records,
-                  grid_mode, predicted ? 1 : 0, nt, nb, two ? grp1 : nullptr, two ? gw : 0u, two ? nullptr : c->qbig);
+                  grid_mode, predicted ? 1 : 0, nt, nb, two ? grp1 : nullptr, two ? gw : 0u, (two || sub) ? nullptr : c->qbig, sub);
         prof_mark(c, "k4_colscan");
         // (one pass: a bin is a bucket and must fit the finish; two: a bin holds the buckets of up to four high parts)
         // The large finish shape (buckets of up to CM4_CAP_BIG records, one workgroup per CU) costs a launch of its own — 6 us on a
         // frame alone even when it has nothing to do — so it is only armed for 16 frames behind a hand-back or a frame that used
         // it; unarmed, any bucket beyond the usual shape's capacity hands the frame back (and arms it).
-        const bool big_armed = !two && c->quant_big_arm > 0;
+        const bool big_armed = !two && !sub && c->quant_big_arm > 0;
         if (c->quant_big_arm) --c->quant_big_arm;
+        // (shared bins: a bin beyond 2^sub finish capacities holds a bucket beyond one; the finish itself checks the buckets)
+        if (sub) cmk4_colscan(st, state, c->h_state_dev, c->qcnt, c->qtot, nt, CM4_CAP << sub, CM4_CAP << sub, nullptr);
+        else
         cmk4_colscan(st, state, c->h_state_dev, c->qcnt, c->qtot, nt, two ? 0xFFFFu : CM4_CAP, two ? 0xFFFFu : (big_armed ? CM4_CAP_BIG : CM4_CAP),
                      two ? nullptr : c->qbig);
         prof_mark(c, "k4_scatter");
         const bool ballot = !c->lds_rank;                // ranks by ballots where the returning LDS adds are not (known to be) lane-ordered
-        cmk4_scatter(st, c->d_frame, c->d_tiles, state, c->qbid, c->qcnt, c->qtot, c->qbofs, nb, c->rec_a, c->records, nt,
-                     predicted ? 1 : 0, c->d_tile_kept, nt, two ? c->dig : nullptr, ballot, two ? nullptr : c->qbig);
+        cmk4_scatter(st, c->d_frame, c->d_tiles, state, c->qbid, c->qcnt, c->qtot, c->qbofs, nbins, c->rec_a, c->records, nt,
+                     predicted ? 1 : 0, c->d_tile_kept, nt, (two || sub) ? c->dig : nullptr, ballot, (two || sub) ? nullptr : c->qbig, sub);
         const void* rec_sorted = c->rec_a;
         void* stage = c->rec_b;
         const uint32_t* bofs = c->qbofs;
@@ -641,7 +649,7 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
         uint32_t* skey = c->out_key ? c->keys_a : nullptr;
         prof_mark(c, "k3_local");
         cmk3_local(st, c->d_frame, state, c->h_state_dev, rec_sorted, c->tile_state, grp_cnt, stage, skey, c->vals_a, false, 0u,
-                   0u, spl, bofs, nb, spl_next, ballot);
+                   0u, spl, bofs, nb, spl_next, ballot, sub, sub ? c->dig : nullptr);
         if (big_armed) {
             // the few buckets that grew beyond what the usual finish workgroup holds (k4_colscan listed them): the large shape
             prof_mark(c, "k3_local(big)");
@@ -908,7 +916,8 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
                             // correct, 440 MB less traffic, but no faster — 0.52 against 0.45-0.50 ms per frame: what the wide
                             // pass adds (search, bucket table, column scan, bucket starts) eats the pass it saves. Off unless
                             // CM_QUANT2=1 (kept for the experiment and its test).
-                            (nb <= CM4_BINS || (c->quant_mode == 2 && g >= 3));
+                            // Default above 2048 buckets: still one pass, 2 or 4 neighbouring buckets to a bin (cm_quant_sub_shift).
+                            (nb <= CM4_BINS || c->quant_sub || (c->quant_mode == 2 && g >= 3));
                 }
                 if (quant && c->quant_off_frames) { --c->quant_off_frames; quant = false; }
                 if (!pre) return launch_bucket(c, gm, g, low, nullptr, nullptr, mode, quant);
@@ -1466,6 +1475,7 @@ int cm_create(cm_ctx** out, int device, const cm_limits* lim) {
     if (const char* dm = getenv("CM_DEBUG_MISRANK")) c->debug_misrank = dm[0] == '1' ? 1 : 0;
 #endif
     if (const char* qm = getenv("CM_QUANT")) c->quant_mode = qm[0] == '0' ? 1 : 0;     // CM_QUANT=0: fixed-grid passes only
+    if (const char* qs = getenv("CM_QUANT_SUB")) c->quant_sub = qs[0] != '0';
     if (const char* q2 = getenv("CM_QUANT2")) if (q2[0] == '1' && c->quant_mode == 0) c->quant_mode = 2;   // also the two-pass variant
     if (!ok) {
         free_all(c);

@@ -55,6 +55,12 @@ static inline uint32_t cm_quant_buckets(uint32_t n) {
     if (b > CM4_BINS && (n + CM4_BINS - 1u) / CM4_BINS <= CM4_MAX_AVG) b = CM4_BINS;
     return b > CM4_MAX_BUCKETS ? CM4_MAX_BUCKETS : b;
 }
+// More than CM4_BINS buckets, still one global pass ("shared bins"): the pass scatters by bucket >> shift — 2^shift
+// neighbouring buckets share a bin — and the finish workgroup of a bucket picks its records out of its bin by their
+// index (k3_local<SUB>: the 2^shift workgroups of a bin run on the same XCD and read it through that XCD's L2).
+static inline uint32_t cm_quant_sub_shift(uint32_t n_buckets) {
+    return n_buckets <= CM4_BINS ? 0u : n_buckets <= 2u * CM4_BINS ? 1u : 2u;
+}
 
 // Point layouts the loaders special-case.
 #define CM_LAYOUT_XYZI16 0    // x,y,z,intensity @0,4,8,12, step 16, 16-B aligned: one dwordx4 load

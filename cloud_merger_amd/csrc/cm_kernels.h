@@ -75,7 +75,9 @@ void cmk3_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t*
                 uint32_t* grp_cnt, void* stage, uint32_t* stage_key, uint32_t* stage_cnt, bool partial, uint32_t low_bits,
                 uint32_t n_slots,                          // n_slots / 2048 workgroups (n_padded, or what the records are expected to need)
                 const uint32_t* spl = nullptr, const uint32_t* bofs = nullptr, uint32_t n_buckets = 0, uint32_t* spl_next = nullptr,
-                bool ballot = false);
+                bool ballot = false,
+                uint32_t sub_shift = 0,                    // shared bins (cm_quant_sub_shift): bofs is per bin, 2^sub_shift buckets each,
+                const unsigned char* dig = nullptr);       // dig[record] = the low sub_shift bits of its bucket number (cmk4_scatter)
 void cmk3_local_big(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* host_state, const void* rec, void* tile_info,
                     uint32_t* grp_cnt, void* stage, uint32_t* stage_key, uint32_t* stage_cnt, const uint32_t* spl, const uint32_t* bofs,
                     uint32_t n_buckets, uint32_t* spl_next, const uint32_t* big_list, bool ballot);
@@ -90,7 +92,8 @@ void cmk4_hist(hipStream_t s, const CmFrameDev& f, CmFrameDev* fd, CmTileDev* ti
                const uint32_t* spl, uint32_t* cnt, uint16_t* bid, unsigned long long* tile_state, uint32_t n_tile_state, float* records,
                int grid_mode, int check_box, uint32_t n_tiles,        // bid: the bucket of every padded slot (0xFFFF: no record)
                uint32_t n_buckets, uint32_t* grp_clear, uint32_t n_grp_clear,    // (> CM4_BINS buckets: the second pass's group totals are cleared here)
-               uint32_t* big_list);                                  // (word 0 zeroed: k4_colscan's list of buckets beyond CM4_CAP)
+               uint32_t* big_list,                                   // (word 0 zeroed: k4_colscan's list of buckets beyond CM4_CAP)
+               uint32_t sub_shift = 0);                              // shared bins (cm_quant_sub_shift): counted per bucket >> sub_shift
 // cap / cap_big / big_list: buckets of (cap, cap_big] records are listed (count, then numbers) for cmk3_local_big; beyond cap_big the frame aborts
 void cmk4_colscan(hipStream_t s, CmFrameState* st, uint32_t* host_state, uint32_t* cnt, uint32_t* totals, uint32_t n_tiles,
                   uint32_t cap, uint32_t cap_big, uint32_t* big_list);
@@ -98,7 +101,8 @@ void cmk4_scatter(hipStream_t s, const CmFrameDev* fd, const CmTileDev* tiles, C
                   const uint32_t* cnt, const uint32_t* totals, uint32_t* bofs, uint32_t n_buckets, void* rec_out,
                   const float* records, uint32_t n_records, int fold, uint32_t* tile_kept, uint32_t n_tiles,
                   unsigned char* dig_out,                              // (> CM4_BINS buckets: the high part of every record's bucket number)
-                  bool ballot = false, const uint32_t* big_list = nullptr);   // (big_list: its count goes into CmFrameState.quant_big)
+                  bool ballot = false, const uint32_t* big_list = nullptr,    // (big_list: its count goes into CmFrameState.quant_big)
+                  uint32_t sub_shift = 0);                             // shared bins: scattered by bucket >> sub_shift, dig_out = the low bits
 // two passes: where every bucket starts once the second pass has run (bofs_lo: what cmk4_scatter left; idtot: CM4_MAX_BUCKETS words)
 void cmk4_bucket_starts(hipStream_t s, CmFrameState* st, uint32_t* host_state, const uint32_t* bofs_lo, const unsigned char* dig,
                         uint32_t* idtot, uint32_t* bofs, uint32_t n_buckets, uint32_t cap);

@@ -90,7 +90,7 @@ __device__ unsigned long long g_phase3[4096 * 16];
 // ------------------------------------------------------------------------------------------------
 // k3_local
 // ------------------------------------------------------------------------------------------------
-template <int LT, int LCAP, int LBLOCK, int WPS, bool PARTIAL, bool QUANT, bool BALLOT>
+template <int LT, int LCAP, int LBLOCK, int WPS, bool PARTIAL, bool QUANT, bool BALLOT, bool SUB>
 __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __restrict__ fd,
                                                       CmFrameState* __restrict__ st,
                                                       uint32_t* __restrict__ host_state,
@@ -103,7 +103,14 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
                                                       uint32_t low_bits,
                                                       const uint32_t* __restrict__ spl, const uint32_t* __restrict__ bofs,
                                                       uint32_t n_buckets, uint32_t* __restrict__ spl_next,
-                                                      const uint32_t* __restrict__ big_list) {
+                                                      const uint32_t* __restrict__ big_list, uint32_t sub_shift,
+                                                      const unsigned char* __restrict__ dig) {
+    // SUB (QUANT, shared bins: cm_device.h cm_quant_sub_shift): the global pass grouped the records by bucket >> sub_shift, so
+    // bucket t's records lie among those of bin t >> sub_shift = records [bofs[bin], bofs[bin + 1]), in stable order, each
+    // with the low bits of its bucket number as a byte beside it (dig). The workgroup reads the bin's bytes, notes the places
+    // of its own records (sp: the "slot" of a record is its number among them) and counts the records of the buckets BELOW
+    // its own: that is where its records would start had the pass grouped by bucket, and where its centroids are staged.
+    // The 2^sub_shift workgroups of a bin are neighbours on one XCD (its lines come out of that XCD's L2 after the first read).
     // big_list (QUANT): word 0 = how many buckets hold more than CM4_CAP records, then their numbers (k4_colscan). The usual
     // launch (big_list == nullptr) leaves those alone; a second launch of the LARGE shape (1024 threads, room for CM4_CAP_BIG
     // records) takes them, workgroup i the i-th of the list: a bucket that doubled or tripled since the last frame costs a
@@ -119,6 +126,8 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
     __shared__ uint32_t whist[LWAVES][HWORDS];         // digit counts per wave
     __shared__ uint32_t lds[2 * LWAVES];
     __shared__ uint32_t s_a, s_keyprev, s_bad, s_njobs;
+    __shared__ uint16_t sp[SUB ? LCAP : 1];            // (SUB) slot -> place in the bin
+    static_assert(!SUB || QUANT, "shared bins are a variant of the quantile finish");
     Job3* jobs = reinterpret_cast<Job3*>(&whist[0][0]);         // (the counters are dead once the sort is over: 512 jobs fit)
 
     if (QUANT && big_list && blockIdx.x >= big_list[0]) return;        // (the large shape's launch: usually nothing to do — leave at once)
@@ -132,6 +141,10 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
     const uint32_t n = SCAL(st->n_valid);
     const uint32_t n_lt = QUANT ? n_buckets : (n + LT - 1) / LT;
     uint32_t tile_ = blockIdx.x;
+    if (SUB) {                                                   // workgroups 8j + x run on XCD x: bin (j >> shift) * 8 + x, bucket j % 2^shift of it
+        const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        tile_ = (((((j >> sub_shift) << 3) + x) << sub_shift) + (j & ((1u << sub_shift) - 1u)));
+    }
     if (QUANT && big_list) {
         if (tile_ >= SCAL(big_list[0])) return;
         tile_ = SCAL(big_list[1 + tile_]);
@@ -143,14 +156,52 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
     const uint32_t min_pts = SCAL((!PARTIAL && fd->min_pts > 1) ? fd->min_pts : 1u);
 
     // ---- load: the nominal tile, the key before it, and the first records after it
-    const uint32_t base = QUANT ? SCAL(bofs[tile]) : tile * LT;
-    const uint32_t q_end = QUANT ? SCAL(bofs[tile + 1]) : 0u;
-    const bool q_big = QUANT && (q_end - base) > static_cast<uint32_t>(LCAP);
+    const uint32_t bin = SUB ? tile >> sub_shift : tile;
+    uint32_t base = QUANT ? SCAL(bofs[bin]) : tile * LT;
+    const uint32_t rbase = base;                                 // slot s is record rbase + s (SUB: rbase + sp[s])
+    const uint32_t q_end = QUANT ? SCAL(bofs[bin + 1]) : 0u;
+    bool q_big = QUANT && !SUB && (q_end - base) > static_cast<uint32_t>(LCAP);
     if (QUANT && q_big && !big_list && (q_end - base) <= CM4_CAP_BIG) return;     // (the large shape's launch takes this bucket)
-    const uint32_t nom = QUANT ? (q_big ? 0u : q_end - base) : min(static_cast<uint32_t>(LT), n - base);
+    uint32_t nom = QUANT ? (q_big ? 0u : q_end - base) : min(static_cast<uint32_t>(LT), n - base);
+    const uint32_t key_end = QUANT ? (fd->box_key_bits < 32u ? (1u << fd->box_key_bits) : 0xFFFFFFFFu) : 0u;
     const uint32_t q_lo = QUANT ? SCAL(spl[tile]) : 0u;
-    const uint32_t q_hi = QUANT ? min(SCAL(spl[tile + 1]), fd->box_key_bits < 32u ? (1u << fd->box_key_bits) : 0xFFFFFFFFu) : 0u;
+    const uint32_t q_hi = QUANT ? min(SCAL(spl[tile + 1]), key_end) : 0u;
     bool q_bad = false;
+    if (SUB) {
+        // dig[p] (k4_scatter): which of its bin's buckets record p belongs to. Sixteen places per thread and round, in order:
+        // the kept records keep the bin's (stable) order. Nothing but these bytes is read of the other buckets' records.
+        const uint32_t sub = tile & ((1u << sub_shift) - 1u);
+        uint32_t kept = 0, below_t = 0;
+        for (uint32_t off = rbase & ~15u; off < q_end; off += 16 * LBLOCK) {
+            const uint32_t p0 = off + 16 * threadIdx.x;
+            uint4 d = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            if (p0 < q_end) d = *reinterpret_cast<const uint4*>(dig + p0);
+            const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
+            uint32_t mm = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t p = p0 + i, v = (dw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                const bool valid = p >= rbase && p < q_end;
+                mm |= (valid && v == sub) ? (1u << i) : 0u;
+                below_t += (valid && v < sub) ? 1u : 0u;
+            }
+            uint32_t tot;
+            uint32_t pos = kept + block_excl_scan3<LWAVES>(static_cast<uint32_t>(__builtin_popcount(mm)), lds, &tot);
+            while (mm) {
+                const uint32_t i = static_cast<uint32_t>(__builtin_ctz(mm));
+                mm &= mm - 1u;
+                if (pos < static_cast<uint32_t>(LCAP)) sp[pos] = static_cast<uint16_t>(p0 + i - rbase);
+                ++pos;
+            }
+            kept += SCAL(tot);
+        }
+        uint32_t below;
+        (void)block_excl_scan3<LWAVES>(below_t, lds, &below);
+        base = rbase + SCAL(below);
+        q_big = kept > static_cast<uint32_t>(LCAP);          // (no large shape behind this one: the frame is handed back)
+        nom = q_big ? 0u : kept;
+        __syncthreads();
+    }
     if (QUANT) {
         // (a bucket holds about 1950 records: four rounds of the workgroup, then — rarely — up to four more)
         constexpr int HALF = LITEMS / 2;
@@ -161,7 +212,7 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
 #pragma unroll
             for (int r = 0; r < HALF; ++r) {
                 const uint32_t q = (h * HALF + r) * LBLOCK + threadIdx.x;
-                r4[r] = (q < nom) ? rec[base + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+                r4[r] = (q < nom) ? rec[rbase + (SUB ? sp[q < nom ? q : 0u] : q)] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int r = 0; r < HALF; ++r) {
@@ -419,7 +470,7 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
 #pragma unroll
         for (int j = 0; j < LITEMS; ++j) {
             if (static_cast<uint32_t>(j) >= per) break;        // (uniform)
-            if ((ldm >> j) & 1u) r4[j] = rec[base + sl[j]];
+            if ((ldm >> j) & 1u) r4[j] = rec[rbase + (SUB ? sp[sl[j]] : sl[j])];
         }
         const uint32_t kid0 = block_excl_scan3<LWAVES>(static_cast<uint32_t>(__builtin_popcount(kheads)), lds, &c_t);
 
@@ -471,7 +522,7 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (static_cast<uint32_t>(u) < nmatch) e4[u] = rec[base + s4[u]];
+                    if (static_cast<uint32_t>(u) < nmatch) e4[u] = rec[rbase + (SUB ? sp[s4[u]] : s4[u])];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (static_cast<uint32_t>(u) < nmatch) {
@@ -515,7 +566,7 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
                 if (idx < n) { r4 = rec[idx]; in = true; }
             } else if (q < m) {
                 const uint32_t sl_ = si[q];
-                if (sk[sl_] == jkey) { r4 = rec[base + sl_]; in = true; }
+                if (sk[sl_] == jkey) { r4 = rec[rbase + (SUB ? sp[sl_] : sl_)]; in = true; }
             }
         };
         // Opening round: most long voxels are not that long (dense ground cells: tens of points), and a wave that takes
@@ -538,7 +589,7 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
                         const uint32_t q = SCAL(jobs[jn].p) + lane;
                         if (q < m) {
                             const uint32_t sl_ = si[q];
-                            if (sk[sl_] == jk[u]) { r4[u] = rec[base + sl_]; in[u] = true; }
+                            if (sk[sl_] == jk[u]) { r4[u] = rec[rbase + (SUB ? sp[sl_] : sl_)]; in[u] = true; }
                         }
                     }
                 }
@@ -692,33 +743,41 @@ extern "C" __attribute__((visibility("default"))) void cm_debug_phases3(unsigned
 
 void cmk3_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* host_state, const void* rec, void* tile_info,
                 uint32_t* grp_cnt, void* stage, uint32_t* stage_key, uint32_t* stage_cnt, bool partial, uint32_t low_bits,
-                uint32_t n_padded, const uint32_t* spl, const uint32_t* bofs, uint32_t n_buckets, uint32_t* spl_next, bool ballot) {
+                uint32_t n_padded, const uint32_t* spl, const uint32_t* bofs, uint32_t n_buckets, uint32_t* spl_next, bool ballot,
+                uint32_t sub_shift, const unsigned char* dig) {
     // 2048-record tiles, room for 4032 (bucket tails of up to 1984 records), 512 threads at no more than 64 registers:
     // 40 912 bytes of LDS — four workgroups per CU, all eight wave slots of every SIMD (44 us at cfg2; with room for 4096 the
     // fourth workgroup does not fit the CU's 160 KiB: 47 us). n_buckets != 0: one workgroup per quantile bucket (cm_kernels_v4.hip).
     // ballot: the LDS sort ranks by ballots instead of returning adds (cm_common.hpp wave_rank_ballot).
     static_assert(CM4_CAP == 4032, "k4_colscan's capacity check is this kernel's LCAP");
-    const dim3 grid(n_buckets ? n_buckets : n_padded / 2048);
-#define CM3_LOCAL(PART, QUANT, BAL, SK, SC, SPL, BOFS, NB, NEXT)                                                                   \
-    hipLaunchKernelGGL((k3_local<2048, 4032, 512, 8, PART, QUANT, BAL>), grid, dim3(512), 0, s, fd, st, host_state,                 \
+    // sub_shift != 0 (shared bins): 2^sub_shift buckets per bin, the workgroups of a bin side by side on one XCD — eight bins
+    // (one per XCD) times 2^sub_shift workgroups per step of the grid; 48.7 KB of LDS (the slots' places in the bin), three per CU
+    const dim3 grid(n_buckets ? (sub_shift ? ((((n_buckets + (1u << sub_shift) - 1u) >> sub_shift) + 7u) / 8u * 8u) << sub_shift : n_buckets)
+                              : n_padded / 2048);
+#define CM3_LOCAL_(PART, QUANT, BAL, SUB, SK, SC, SPL, BOFS, NB, NEXT)                                                              \
+    hipLaunchKernelGGL((k3_local<2048, 4032, 512, 8, PART, QUANT, BAL, SUB>), grid, dim3(512), 0, s, fd, st, host_state,            \
                        reinterpret_cast<const float4*>(rec), reinterpret_cast<uint2*>(tile_info), grp_cnt,                          \
-                       reinterpret_cast<float4*>(stage), SK, SC, low_bits, SPL, BOFS, NB, NEXT, nullptr)
-    if (n_buckets) { if (ballot) CM3_LOCAL(false, true, true, stage_key, stage_cnt, spl, bofs, n_buckets, spl_next);
+                       reinterpret_cast<float4*>(stage), SK, SC, low_bits, SPL, BOFS, NB, NEXT, nullptr, sub_shift, dig)
+#define CM3_LOCAL(PART, QUANT, BAL, SK, SC, SPL, BOFS, NB, NEXT) CM3_LOCAL_(PART, QUANT, BAL, false, SK, SC, SPL, BOFS, NB, NEXT)
+    if (n_buckets && sub_shift) { if (ballot) CM3_LOCAL_(false, true, true, true, stage_key, stage_cnt, spl, bofs, n_buckets, spl_next);
+                                  else CM3_LOCAL_(false, true, false, true, stage_key, stage_cnt, spl, bofs, n_buckets, spl_next); }
+    else if (n_buckets) { if (ballot) CM3_LOCAL(false, true, true, stage_key, stage_cnt, spl, bofs, n_buckets, spl_next);
                      else CM3_LOCAL(false, true, false, stage_key, stage_cnt, spl, bofs, n_buckets, spl_next); }
     else if (partial) { if (ballot) CM3_LOCAL(true, false, true, nullptr, nullptr, nullptr, nullptr, 0u, nullptr);
                         else CM3_LOCAL(true, false, false, nullptr, nullptr, nullptr, nullptr, 0u, nullptr); }
     else { if (ballot) CM3_LOCAL(false, false, true, stage_key, stage_cnt, nullptr, nullptr, 0u, spl_next);
            else CM3_LOCAL(false, false, false, stage_key, stage_cnt, nullptr, nullptr, 0u, spl_next); }
 #undef CM3_LOCAL
+#undef CM3_LOCAL_
 }
 
 // The buckets of a quantile frame that hold more than CM4_CAP records (big_list: k4_colscan), one workgroup of the large shape each.
 void cmk3_local_big(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t* host_state, const void* rec, void* tile_info,
                     uint32_t* grp_cnt, void* stage, uint32_t* stage_key, uint32_t* stage_cnt, const uint32_t* spl, const uint32_t* bofs,
                     uint32_t n_buckets, uint32_t* spl_next, const uint32_t* big_list, bool ballot) {
-#define CM3_BIG(BAL) hipLaunchKernelGGL((k3_local<4096, CM4_CAP_BIG, 1024, 4, false, true, BAL>), dim3(CM4_MAX_BIG), dim3(1024), 0, s, fd, st,   \
+#define CM3_BIG(BAL) hipLaunchKernelGGL((k3_local<4096, CM4_CAP_BIG, 1024, 4, false, true, BAL, false>), dim3(CM4_MAX_BIG), dim3(1024), 0, s, fd, st,   \
                                         host_state, reinterpret_cast<const float4*>(rec), reinterpret_cast<uint2*>(tile_info), grp_cnt,         \
-                                        reinterpret_cast<float4*>(stage), stage_key, stage_cnt, 0u, spl, bofs, n_buckets, spl_next, big_list)
+                                        reinterpret_cast<float4*>(stage), stage_key, stage_cnt, 0u, spl, bofs, n_buckets, spl_next, big_list, 0u, nullptr)
     if (ballot) CM3_BIG(true); else CM3_BIG(false);
 #undef CM3_BIG
 }

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(CM2_BLOCK) void k4_hist(const CmFrameDev fv, CmFram
                                                      unsigned long long* __restrict__ tile_state, uint32_t n_tile_state,
                                                      float* __restrict__ records, int grid_mode, int check_box,
                                                      uint32_t* __restrict__ grp_clear, uint32_t n_grp_clear, uint32_t n_passes,
-                                                     uint32_t* __restrict__ big_list) {
+                                                     uint32_t* __restrict__ big_list, uint32_t bin_shift) {
     __shared__ uint32_t spl[1 << LEVELS];
     __shared__ uint32_t lh[CM4_BINS / 2];
     __shared__ float s_mm[CM2_WAVES][6];
@@ -236,9 +236,10 @@ __global__ __launch_bounds__(CM2_BLOCK) void k4_hist(const CmFrameDev fv, CmFram
 #pragma unroll
     for (int r = 0; r < CM2_ITEMS; ++r) {
         // (a slot without a record adds nothing, to a word of its own: same-address LDS adds of a wave serialise;
-        // the counters are per LOW eleven bits of the bucket number: what this pass scatters by)
+        // the counters are per bin — what this pass scatters by: with more than CM4_BINS buckets the bucket number without
+        // its low bin_shift bits (shared bins, cm_device.h) or, bin_shift == 0, its low eleven bits (two passes))
         const bool keep = (keepm >> r) & 1u;
-        const uint32_t lo = bk[r] & (CM4_BINS - 1);
+        const uint32_t lo = bin_shift ? bk[r] >> bin_shift : bk[r] & (CM4_BINS - 1);
         atomicAdd(&lh[keep ? lo >> 1 : static_cast<uint32_t>(lane)], (keep ? 1u : 0u) << ((lo & 1u) * 16u));
         // the bucket of every slot (0xFFFF: no record), so that k4_scatter neither tests nor searches a second time
         bid[slot0 + r * 64] = static_cast<uint16_t>(keep ? bk[r] : 0xFFFFu);
@@ -380,9 +381,13 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k4_scatter(const CmFrameDev* __r
                                                            uint32_t* __restrict__ bofs, uint32_t n_buckets,
                                                            float4* __restrict__ rec_out, const float* __restrict__ records,
                                                            uint32_t n_records, int fold, uint32_t* __restrict__ tile_kept,
-                                                           unsigned char* __restrict__ dig_out, const uint32_t* __restrict__ big_list) {
+                                                           unsigned char* __restrict__ dig_out, const uint32_t* __restrict__ big_list,
+                                                           uint32_t sub_shift) {
     // TWO: the bucket numbers have up to thirteen bits; this pass scatters by the low eleven and leaves the high ones as a
-    // byte beside every record (dig_out), for the second pass (k2_hist + k2_scatter<false>: cm_kernels_v2.hip).
+    // byte beside every record (dig_out), for the second pass (k2_hist + k2_scatter<false>: cm_kernels_v2.hip) — or, shared
+    // bins (sub_shift != 0, cm_device.h), by all but the low sub_shift bits and leaves THOSE: which of its bin's buckets a
+    // record belongs to, for the finish (k3_local<SUB>).
+    auto bin_of = [&](uint32_t id) { return (TWO && sub_shift) ? id >> sub_shift : id & (CM4_BINS - 1); };
     constexpr int HW = CM4_BINS / 2;                      // counter words per wave
     constexpr int STG = 2048;                             // staged records per round
     __shared__ uint32_t buf[STG * 4 + STG / 2];           // per-wave counters (8 x HW) | staging: records + buckets
@@ -444,7 +449,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k4_scatter(const CmFrameDev* __r
     if (BALLOT) {                                          // (ranking by ballots: cm_common.hpp wave_rank_ballot)
 #pragma unroll
         for (int r = 0; r < CM2_ITEMS; ++r)
-            bk[r] |= wave_rank_ballot(wcnt[w], bk[r] & (CM4_BINS - 1), 11u, (vmask >> r) & 1u, lane) << 16;
+            bk[r] |= wave_rank_ballot(wcnt[w], bin_of(bk[r]), 11u, (vmask >> r) & 1u, lane) << 16;
     } else {
 #pragma unroll
     for (int r0 = 0; r0 < CM2_ITEMS; r0 += 4) {
@@ -452,12 +457,12 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k4_scatter(const CmFrameDev* __r
 #pragma unroll
         for (int r = r0; r < r0 + 4; ++r) {
             const bool has = (vmask >> r) & 1u;
-            const uint32_t lo = bk[r] & (CM4_BINS - 1);
+            const uint32_t lo = bin_of(bk[r]);
             got[r - r0] = atomicAdd(&wcnt[w][has ? lo >> 1 : static_cast<uint32_t>(lane)], (has ? 1u : 0u) << ((lo & 1u) * 16u));
         }
 #pragma unroll
         for (int r = r0; r < r0 + 4; ++r) {
-            bk[r] |= ((got[r - r0] >> ((bk[r] & 1u) * 16u)) & 0xFFFFu) << 16;
+            bk[r] |= ((got[r - r0] >> ((bin_of(bk[r]) & 1u) * 16u)) & 0xFFFFu) << 16;
             asm volatile("" : "+v"(bk[r]));                 // (formed here: the raw returns need not stay alive)
         }
     }
@@ -499,9 +504,9 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k4_scatter(const CmFrameDev* __r
     // (now bk[r] = bucket | sorted position in the tile << 16; a slot without a record: position 0xFFFF, beyond every round)
 #pragma unroll
     for (int r = 0; r < CM2_ITEMS; ++r) {
-        const uint32_t bq = bk[r] & 0xFFFFu;
-        const uint32_t wv = wcnt[w][(bq & (CM4_BINS - 1)) >> 1];
-        const uint32_t at = ((wv >> ((bq & 1u) * 16u)) & 0xFFFFu) + (bk[r] >> 16);
+        const uint32_t bq = bk[r] & 0xFFFFu, bn_ = bin_of(bq);
+        const uint32_t wv = wcnt[w][bn_ >> 1];
+        const uint32_t at = ((wv >> ((bn_ & 1u) * 16u)) & 0xFFFFu) + (bk[r] >> 16);
         bk[r] = bq | ((((vmask >> r) & 1u) ? at : 0xFFFFu) << 16);
     }
 #pragma unroll
@@ -521,9 +526,9 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k4_scatter(const CmFrameDev* __r
             const uint32_t t = lo + j * CM2_BLOCK + threadIdx.x;
             if (t < tile_valid) {
                 const uint32_t id = sbk[t - lo];
-                const uint32_t pos = gofs[id & (CM4_BINS - 1)] + t;
+                const uint32_t pos = gofs[bin_of(id)] + t;
                 rec_out[pos] = srec[t - lo];
-                if (TWO) dig_out[pos] = static_cast<unsigned char>(id >> 11);
+                if (TWO) dig_out[pos] = static_cast<unsigned char>(sub_shift ? id & ((1u << sub_shift) - 1u) : id >> 11);
             }
         }
     }
@@ -600,10 +605,11 @@ __global__ __launch_bounds__(1024) void k4_idscan(CmFrameState* __restrict__ st,
 void cmk4_hist(hipStream_t s, const CmFrameDev& f, CmFrameDev* fd, CmTileDev* tiles, bool do_setup, CmFrameState* st,
                const uint32_t* spl, uint32_t* cnt, uint16_t* bid, unsigned long long* tile_state, uint32_t n_tile_state, float* records,
                int grid_mode, int check_box, uint32_t n_tiles, uint32_t n_buckets, uint32_t* grp_clear, uint32_t n_grp_clear,
-               uint32_t* big_list) {
-    const uint32_t np = n_buckets > CM4_BINS ? 2u : 1u;
+               uint32_t* big_list, uint32_t sub_shift) {
+    // sub_shift != 0: shared bins — counted per bucket >> sub_shift (<= CM4_BINS bins), one pass
+    const uint32_t np = (n_buckets > CM4_BINS && !sub_shift) ? 2u : 1u;
 #define CM4_HIST(L) hipLaunchKernelGGL(k4_hist<L>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, f, fd, tiles, do_setup ? 1 : 0, st, spl, cnt, bid, \
-                                       tile_state, n_tile_state, records, grid_mode, check_box, grp_clear, n_grp_clear, np, big_list)
+                                       tile_state, n_tile_state, records, grid_mode, check_box, grp_clear, n_grp_clear, np, big_list, sub_shift)
     if (n_buckets <= 2048) CM4_HIST(11);
     else if (n_buckets <= 4096) CM4_HIST(12);
     else CM4_HIST(13);
@@ -619,10 +625,11 @@ void cmk4_colscan(hipStream_t s, CmFrameState* st, uint32_t* host_state, uint32_
 void cmk4_scatter(hipStream_t s, const CmFrameDev* fd, const CmTileDev* tiles, CmFrameState* st, const uint16_t* bid,
                   const uint32_t* cnt, const uint32_t* totals, uint32_t* bofs, uint32_t n_buckets, void* rec_out,
                   const float* records, uint32_t n_records, int fold, uint32_t* tile_kept, uint32_t n_tiles, unsigned char* dig_out,
-                  bool ballot, const uint32_t* big_list) {
+                  bool ballot, const uint32_t* big_list, uint32_t sub_shift) {
 #define CM4_SCATTER(TWO, BAL, DIG) hipLaunchKernelGGL((k4_scatter<TWO, BAL>), dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, bid, cnt, totals, \
-                                                      bofs, n_buckets, reinterpret_cast<float4*>(rec_out), records, n_records, fold, tile_kept, DIG, big_list)
-    if (n_buckets > CM4_BINS) { if (ballot) CM4_SCATTER(true, true, dig_out); else CM4_SCATTER(true, false, dig_out); }
+                                                      bofs, n_buckets, reinterpret_cast<float4*>(rec_out), records, n_records, fold, tile_kept, DIG, big_list, \
+                                                      sub_shift)
+    if (dig_out) { if (ballot) CM4_SCATTER(true, true, dig_out); else CM4_SCATTER(true, false, dig_out); }
     else { if (ballot) CM4_SCATTER(false, true, nullptr); else CM4_SCATTER(false, false, nullptr); }
 #undef CM4_SCATTER
 }

@@ -109,14 +109,15 @@ def config2_stream(frame, n_per_sensor=1_000_000, n_sensors=4, min_pts=0, wide=F
     return sensors, MergeParams(leaf=(0.05,) * 3, min_points_per_voxel=min_pts)
 
 
-def config3_dense(n_per_sensor=2_000_000, n_sensors=8, min_pts=0, leaf=0.02):
+def config3_dense(n_per_sensor=2_000_000, n_sensors=8, min_pts=0, leaf=0.02, draw=0):
     """cfg3's sensors, box and leaf with the points drawn INSIDE the reference ROI (about 85 % survive the crop instead of
     4 %): 13-14 M records of 29-bit indices enter the sort — the LDS/sort stress BASELINE.json's configs[2] names.
-    Vehicle-mounted sensors (yaw-only poses); every sensor sees the whole corridor."""
+    Vehicle-mounted sensors (yaw-only poses); every sensor sees the whole corridor. draw: another draw of the same scene
+    (fresh points; draw 0 is the frame the tests and the static loop use) — bench.py's moving dense stream."""
     sensors = []
     lo, hi = np.asarray(REF_ROI_MIN, np.float64), np.asarray(REF_ROI_MAX, np.float64)
     for s in range(n_sensors):
-        rng = _rng(3501 + s)
+        rng = _rng(3501 + s + 7919 * draw)
         yaw = rng.uniform(-np.pi, np.pi)
         q = yaw_quaternion(yaw)
         t = rng.uniform(-2, 2, 3)
