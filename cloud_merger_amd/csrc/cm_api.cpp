@@ -171,8 +171,8 @@ struct cm_ctx {
     bool pub_pending[2] = {false, false};
 
     // quantile passes (cm_kernels_v4.hip): one global pass into buckets cut at the last frame's quantiles
-    bool quant_sub = true;               // CM_QUANT_SUB=0: frames above 2048 buckets take the fixed-grid passes (or CM_QUANT2's two)
-    int quant_mode = 0;                  // CM_QUANT: 0 auto, 1 never; 2 (CM_QUANT2=1): auto, and two passes for frames above 2048 buckets
+    bool quant_sub = true;               // CM_QUANT_SUB=0: frames above 2048 buckets take the fixed-grid passes
+    int quant_mode = 0;                  // CM_QUANT: 0 auto, 1 never
     uint32_t* spl[2] = {nullptr, nullptr};   // splitters: a frame reads spl[spl_cur]; its finish writes spl[spl_cur ^ 1]
     int spl_cur = 0;
     bool spl_valid = false;              // spl[spl_cur] holds the quantiles of the last finished frame
@@ -180,7 +180,6 @@ struct cm_ctx {
     int32_t spl_min_b[3] = {0, 0, 0}, spl_div_b[3] = {0, 0, 0};   // ... as indices of this grid
     float spl_inv_leaf[3] = {0, 0, 0};
     uint32_t *qcnt = nullptr, *qtot = nullptr, *qbofs = nullptr;  // per-tile bucket counts / prefixes, bucket totals, bucket starts
-    uint32_t *qidtot = nullptr, *qbofs2 = nullptr;                // two passes: totals per bucket number, bucket starts behind the second pass
     uint32_t* qbig = nullptr;                                     // buckets beyond CM4_CAP records: count, then their numbers
     uint32_t quant_big_arm = 0;          // quantile frames for which the large finish shape is still launched (armed by a hand-back or a listed bucket)
     uint16_t* qbid = nullptr;            // the bucket of every padded slot
@@ -300,7 +299,7 @@ void free_all(cm_ctx* c) {
     F(c->keys_a); F(c->keys_b); F(c->vals_a); F(c->vals_b); F(c->hist); F(c->totals);
     F(c->seg_counts); F(c->seg_tile_counts); F(c->seg_groups); F(c->grp); F(c->partials); F(c->out_key); F(c->out_cnt); F(c->merged_total); F(c->out); F(c->merged); F(c->partial); F(c->table_entries); F(c->mask); F(c->sorted_pts); F(c->rows); F(c->d_state_o);
     F(c->stage32); F(c->out32); F(c->rec_a); F(c->rec_b); F(c->dig); F(c->tile_state); F(c->wave_cnt); F(c->records);
-    F(c->spl[0]); F(c->spl[1]); F(c->qcnt); F(c->qtot); F(c->qbofs); F(c->qbid); F(c->qidtot); F(c->qbofs2); F(c->qbig);
+    F(c->spl[0]); F(c->spl[1]); F(c->qcnt); F(c->qtot); F(c->qbofs); F(c->qbid); F(c->qbig);
     F(c->out_other); F(c->out32_other);
     if (c->pub_stream) (void)hipStreamDestroy(c->pub_stream);
     for (auto e : c->ev_pub) if (e) (void)hipEventDestroy(e);
@@ -549,8 +548,6 @@ int bucket_buffers(cm_ctx* c) {
     if (!c->qtot) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->qtot), CM4_BINS * 4));
     if (!c->qbid) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->qbid), static_cast<size_t>(std::min<uint32_t>(c->cap_tiles, CM4_MAX_TILES)) * CM_TILE * 2));
     if (!c->qbofs) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->qbofs), (CM4_BINS + 4) * 4));
-    if (!c->qidtot) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->qidtot), CM4_MAX_BUCKETS * 4));
-    if (!c->qbofs2) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->qbofs2), (CM4_MAX_BUCKETS + 4) * 4));
     if (!c->qbig) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->qbig), (CM4_MAX_BIG + 4) * 4));
     return CM_OK;
 }
@@ -597,53 +594,31 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
         c->frame_mask = nullptr;
         const uint32_t nt = f.n_tiles;
         const uint32_t nb = cm_quant_buckets(c->spl_n);
-        // more buckets than the pass has bins: 2^sub neighbouring buckets share a bin and the finish picks its records out of
-        // it (k3_local<SUB>) — or, CM_QUANT2=1, a second, narrow pass
-        const bool two = nb > CM4_BINS && c->quant_mode == 2;
-        const uint32_t sub = (nb > CM4_BINS && !two) ? cm_quant_sub_shift(nb) : 0u;
-        const uint32_t nbins = sub ? (nb + (1u << sub) - 1u) >> sub : nb;
+        // more buckets than the pass has bins: 2^sub neighbouring buckets share a bin, the pass leaves the low bits of every
+        // record's bucket number as a byte beside it (c->dig) and the finish picks its records out of the bin (k3_local<SUB>)
+        const uint32_t sub = cm_quant_sub_shift(nb);
+        const uint32_t nbins = (nb + (1u << sub) - 1u) >> sub;
         const uint32_t* spl = c->spl[c->spl_cur];
         uint32_t* spl_next = c->spl[c->spl_cur ^ 1];
-        const uint32_t n_groups = (nt + CM_GROUP - 1) / CM_GROUP;
-        const uint32_t gw = n_groups * CM_RADIX;
-        const size_t gstride = static_cast<size_t>(c->cap_groups) * CM_RADIX;
-        uint32_t* grp1 = c->grp + 2 * gstride;           // the second pass's group totals (k2_hist accumulates: cleared by k4_hist)
         prof_mark(c, "k4_hist");
         cmk4_hist(st, f, c->d_frame, c->d_tiles, do_setup_q, state, spl, c->qcnt, c->qbid, c->tile_state, f.n_padded / 1024 + 2, c->records,
-                  grid_mode, predicted ? 1 : 0, nt, nb, two ? grp1 : nullptr, two ? gw : 0u, (two || sub) ? nullptr : c->qbig, sub);
+                  grid_mode, predicted ? 1 : 0, nt, nb, sub ? nullptr : c->qbig, sub);
         prof_mark(c, "k4_colscan");
-        // (one pass: a bin is a bucket and must fit the finish; two: a bin holds the buckets of up to four high parts)
         // The large finish shape (buckets of up to CM4_CAP_BIG records, one workgroup per CU) costs a launch of its own — 6 us on a
         // frame alone even when it has nothing to do — so it is only armed for 16 frames behind a hand-back or a frame that used
         // it; unarmed, any bucket beyond the usual shape's capacity hands the frame back (and arms it).
-        const bool big_armed = !two && !sub && c->quant_big_arm > 0;
+        const bool big_armed = !sub && c->quant_big_arm > 0;
         if (c->quant_big_arm) --c->quant_big_arm;
         // (shared bins: a bin beyond 2^sub finish capacities holds a bucket beyond one; the finish itself checks the buckets)
         if (sub) cmk4_colscan(st, state, c->h_state_dev, c->qcnt, c->qtot, nt, CM4_CAP << sub, CM4_CAP << sub, nullptr);
-        else
-        cmk4_colscan(st, state, c->h_state_dev, c->qcnt, c->qtot, nt, two ? 0xFFFFu : CM4_CAP, two ? 0xFFFFu : (big_armed ? CM4_CAP_BIG : CM4_CAP),
-                     two ? nullptr : c->qbig);
+        else cmk4_colscan(st, state, c->h_state_dev, c->qcnt, c->qtot, nt, CM4_CAP, big_armed ? CM4_CAP_BIG : CM4_CAP, c->qbig);
         prof_mark(c, "k4_scatter");
         const bool ballot = !c->lds_rank;                // ranks by ballots where the returning LDS adds are not (known to be) lane-ordered
         cmk4_scatter(st, c->d_frame, c->d_tiles, state, c->qbid, c->qcnt, c->qtot, c->qbofs, nbins, c->rec_a, c->records, nt,
-                     predicted ? 1 : 0, c->d_tile_kept, nt, (two || sub) ? c->dig : nullptr, ballot, (two || sub) ? nullptr : c->qbig, sub);
+                     predicted ? 1 : 0, c->d_tile_kept, nt, sub ? c->dig : nullptr, ballot, sub ? nullptr : c->qbig, sub);
         const void* rec_sorted = c->rec_a;
         void* stage = c->rec_b;
         const uint32_t* bofs = c->qbofs;
-        if (two) {
-            prof_mark(c, "k4_idcount");
-            cmk4_bucket_starts(st, state, c->h_state_dev, c->qbofs, c->dig, c->qidtot, c->qbofs2, nb, CM4_CAP);
-            const bool big_p = n_groups > CM_DIRECT_GROUPS;
-            prof_mark(c, "k2_hist");
-            cmk2_hist(st, state, c->dig, c->hist, grp1, nt);
-            if (big_p) { prof_mark(c, "k_gscan"); cmk_gscan(st, state, grp1, c->totals, 1, n_groups); }
-            prof_mark(c, "k2_scatter");
-            cmk2_scatter(st, false, c->d_frame, c->d_tiles, state, c->rec_a, c->rec_b, c->dig, c->hist, grp1, big_p ? c->totals : nullptr,
-                         0u, 32u, nt, n_groups, f.n_padded, c->records, nt, 0, nullptr, 0, nullptr, nullptr, 0, nullptr, false, ballot);
-            rec_sorted = c->rec_b;
-            stage = c->rec_a;
-            bofs = c->qbofs2;
-        }
         // (tile_info: one word pair per bucket; the group totals of the kept voxels behind them — nb + nb / 128 + 1 <= n_padded / 1024 + 2)
         uint32_t* grp_cnt = reinterpret_cast<uint32_t*>(c->tile_state + nb);
         uint32_t* skey = c->out_key ? c->keys_a : nullptr;
@@ -911,13 +886,9 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
                 if (quant) {
                     const uint32_t nb = cm_quant_buckets(c->spl_n);
                     quant = nb != 0 && c->spl_n / nb <= CM4_MAX_AVG && est <= 2ull * c->spl_n + CM_TILE &&
-                            // Above 2048 buckets the quantile passes are two (wide by the low bits of the bucket number, narrow
-                            // by the high ones). Measured on cfg3's dense variant (13.7 M records, three fixed-grid passes):
-                            // correct, 440 MB less traffic, but no faster — 0.52 against 0.45-0.50 ms per frame: what the wide
-                            // pass adds (search, bucket table, column scan, bucket starts) eats the pass it saves. Off unless
-                            // CM_QUANT2=1 (kept for the experiment and its test).
-                            // Default above 2048 buckets: still one pass, 2 or 4 neighbouring buckets to a bin (cm_quant_sub_shift).
-                            (nb <= CM4_BINS || c->quant_sub || (c->quant_mode == 2 && g >= 3));
+                            // Above 2048 buckets: still one pass, 2 or 4 neighbouring buckets to a bin (cm_device.h cm_quant_sub_shift;
+                            // cfg3's dense variant, 13.7 M records: 0.38-0.41 against 0.46-0.50 ms per frame for three fixed-grid passes).
+                            (nb <= CM4_BINS || c->quant_sub);
                 }
                 if (quant && c->quant_off_frames) { --c->quant_off_frames; quant = false; }
                 if (!pre) return launch_bucket(c, gm, g, low, nullptr, nullptr, mode, quant);
@@ -1476,7 +1447,6 @@ int cm_create(cm_ctx** out, int device, const cm_limits* lim) {
 #endif
     if (const char* qm = getenv("CM_QUANT")) c->quant_mode = qm[0] == '0' ? 1 : 0;     // CM_QUANT=0: fixed-grid passes only
     if (const char* qs = getenv("CM_QUANT_SUB")) c->quant_sub = qs[0] != '0';
-    if (const char* q2 = getenv("CM_QUANT2")) if (q2[0] == '1' && c->quant_mode == 0) c->quant_mode = 2;   // also the two-pass variant
     if (!ok) {
         free_all(c);
         delete c;

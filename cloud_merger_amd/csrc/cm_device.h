@@ -36,8 +36,8 @@
 // Quantile passes (cm_kernels_v4.hip): ONE global pass into up to CM4_BINS buckets cut at the quantiles of the previous
 // frame's sorted records (about CM4_TARGET records each), one finish workgroup per bucket (room for CM4_CAP records).
 #define CM4_BINS 2048         // bins of the wide pass
-#define CM4_MAX_BUCKETS 8192  // buckets of a frame: above CM4_BINS the wide pass scatters by the low eleven bits of the bucket number
-                              // and a second, narrow pass by the high ones (frames of up to 15 M records)
+#define CM4_MAX_BUCKETS 8192  // buckets of a frame: above CM4_BINS two or four neighbouring buckets share a bin of the pass
+                              // (cm_quant_sub_shift below; frames of up to 15 M records)
 #define CM4_TARGET 1920u
 #define CM4_CAP 4032u          // records a finish workgroup of the usual shape holds (k3_local: 512 threads, four per CU)
 #define CM4_CAP_BIG 8064u      // ... and of the large shape (1024 threads, one per CU) that takes the few buckets beyond that

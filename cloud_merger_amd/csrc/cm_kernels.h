@@ -91,7 +91,7 @@ void cmk3_compact(hipStream_t s, const CmFrameState* st, CmFrameState* st_next, 
 void cmk4_hist(hipStream_t s, const CmFrameDev& f, CmFrameDev* fd, CmTileDev* tiles, bool do_setup, CmFrameState* st,
                const uint32_t* spl, uint32_t* cnt, uint16_t* bid, unsigned long long* tile_state, uint32_t n_tile_state, float* records,
                int grid_mode, int check_box, uint32_t n_tiles,        // bid: the bucket of every padded slot (0xFFFF: no record)
-               uint32_t n_buckets, uint32_t* grp_clear, uint32_t n_grp_clear,    // (> CM4_BINS buckets: the second pass's group totals are cleared here)
+               uint32_t n_buckets,
                uint32_t* big_list,                                   // (word 0 zeroed: k4_colscan's list of buckets beyond CM4_CAP)
                uint32_t sub_shift = 0);                              // shared bins (cm_quant_sub_shift): counted per bucket >> sub_shift
 // cap / cap_big / big_list: buckets of (cap, cap_big] records are listed (count, then numbers) for cmk3_local_big; beyond cap_big the frame aborts
@@ -100,12 +100,9 @@ void cmk4_colscan(hipStream_t s, CmFrameState* st, uint32_t* host_state, uint32_
 void cmk4_scatter(hipStream_t s, const CmFrameDev* fd, const CmTileDev* tiles, CmFrameState* st, const uint16_t* bid,
                   const uint32_t* cnt, const uint32_t* totals, uint32_t* bofs, uint32_t n_buckets, void* rec_out,
                   const float* records, uint32_t n_records, int fold, uint32_t* tile_kept, uint32_t n_tiles,
-                  unsigned char* dig_out,                              // (> CM4_BINS buckets: the high part of every record's bucket number)
+                  unsigned char* dig_out,                              // (shared bins: the low sub_shift bits of every record's bucket number)
                   bool ballot = false, const uint32_t* big_list = nullptr,    // (big_list: its count goes into CmFrameState.quant_big)
                   uint32_t sub_shift = 0);                             // shared bins: scattered by bucket >> sub_shift, dig_out = the low bits
-// two passes: where every bucket starts once the second pass has run (bofs_lo: what cmk4_scatter left; idtot: CM4_MAX_BUCKETS words)
-void cmk4_bucket_starts(hipStream_t s, CmFrameState* st, uint32_t* host_state, const uint32_t* bofs_lo, const unsigned char* dig,
-                        uint32_t* idtot, uint32_t* bofs, uint32_t n_buckets, uint32_t cap);
 
 // ---- zone-wise ground removal (cm_kernels_ground.hip) ------------------------------------------
 void cmkg_setup(hipStream_t s, const CmGroundDev& g, CmGroundDev* d_ground);

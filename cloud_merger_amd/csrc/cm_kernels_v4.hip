@@ -59,9 +59,9 @@ __device__ __forceinline__ uint32_t block_excl_scan4(uint32_t v, uint32_t* lds, 
 static_assert(CM4_BINS == 2048 && CM4_MAX_BUCKETS == 8192, "eleven to thirteen levels");
 // (nodes numbered from 1, heap fashion: children of node b are 2b and 2b + 1, so a step is b = 2b + (tree[b] <= key) — one
 // add-with-carry behind the compare; word 0 of the tree is unused. After LEVELS steps b - 2^LEVELS is the bucket.)
-// LEVELS = 11: up to 2048 buckets, one global pass. 12, 13: up to 8192 buckets for frames of up to 15 M records — the pass
-// then scatters by the low eleven bits of the bucket number and a second, narrow pass (k2_scatter by the byte this one
-// leaves beside every record) by the high ones: a stable LSD sort by bucket, two passes where the fixed grid takes three.
+// LEVELS = 11: up to 2048 buckets. 12, 13: up to 8192 buckets for frames of up to 15 M records — 2 or 4 neighbouring buckets
+// then share one of the pass's 2048 bins (cm_device.h cm_quant_sub_shift): the pass scatters by bucket >> shift and leaves
+// the low bits as a byte beside every record; the finish workgroup of a bucket picks its records out of its bin by them.
 template <int LEVELS>
 __device__ __forceinline__ void load_splitter_tree(uint32_t* __restrict__ tree, const uint32_t* __restrict__ spl_g) {
 #pragma unroll
@@ -146,7 +146,6 @@ __global__ __launch_bounds__(CM2_BLOCK) void k4_hist(const CmFrameDev fv, CmFram
                                                      uint32_t* __restrict__ cnt, uint16_t* __restrict__ bid,
                                                      unsigned long long* __restrict__ tile_state, uint32_t n_tile_state,
                                                      float* __restrict__ records, int grid_mode, int check_box,
-                                                     uint32_t* __restrict__ grp_clear, uint32_t n_grp_clear, uint32_t n_passes,
                                                      uint32_t* __restrict__ big_list, uint32_t bin_shift) {
     __shared__ uint32_t spl[1 << LEVELS];
     __shared__ uint32_t lh[CM4_BINS / 2];
@@ -173,8 +172,6 @@ __global__ __launch_bounds__(CM2_BLOCK) void k4_hist(const CmFrameDev fv, CmFram
             reinterpret_cast<uint32_t*>(fd_dst)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&fv)[threadIdx.x];
     }
     for (uint32_t k = tile * CM2_BLOCK + threadIdx.x; k < n_tile_state; k += gridDim.x * CM2_BLOCK) tile_state[k] = 0ull;
-    // (two passes: the group totals k2_hist accumulates for the second one)
-    for (uint32_t k = tile * CM2_BLOCK + threadIdx.x; k < n_grp_clear; k += gridDim.x * CM2_BLOCK) grp_clear[k] = 0;
     if (tile == 0 && threadIdx.x == 0) {                 // the box and its grid, as the host set them up
         st->status = CM_DEV_OK;
         for (int a = 0; a < 3; ++a) {
@@ -185,7 +182,7 @@ __global__ __launch_bounds__(CM2_BLOCK) void k4_hist(const CmFrameDev fv, CmFram
             st->div_b[a] = db;
         }
         st->key_bits = fd->box_key_bits;
-        st->n_passes = n_passes;
+        st->n_passes = 1u;
         if (big_list) big_list[0] = 0u;                    // (k4_colscan's list of buckets for the large finish shape)
     }
     const BoxGrid b = box_grid_of(fd);
@@ -236,10 +233,10 @@ __global__ __launch_bounds__(CM2_BLOCK) void k4_hist(const CmFrameDev fv, CmFram
 #pragma unroll
     for (int r = 0; r < CM2_ITEMS; ++r) {
         // (a slot without a record adds nothing, to a word of its own: same-address LDS adds of a wave serialise;
-        // the counters are per bin — what this pass scatters by: with more than CM4_BINS buckets the bucket number without
-        // its low bin_shift bits (shared bins, cm_device.h) or, bin_shift == 0, its low eleven bits (two passes))
+        // the counters are per bin — what this pass scatters by: the bucket number without its low bin_shift bits
+        // (shared bins above CM4_BINS buckets, cm_device.h; bin_shift == 0: a bin is a bucket))
         const bool keep = (keepm >> r) & 1u;
-        const uint32_t lo = bin_shift ? bk[r] >> bin_shift : bk[r] & (CM4_BINS - 1);
+        const uint32_t lo = bk[r] >> bin_shift;
         atomicAdd(&lh[keep ? lo >> 1 : static_cast<uint32_t>(lane)], (keep ? 1u : 0u) << ((lo & 1u) * 16u));
         // the bucket of every slot (0xFFFF: no record), so that k4_scatter neither tests nor searches a second time
         bid[slot0 + r * 64] = static_cast<uint16_t>(keep ? bk[r] : 0xFFFFu);
@@ -308,7 +305,8 @@ __global__ __launch_bounds__(1024) void k4_colscan(CmFrameState* __restrict__ st
                                                    uint32_t n_tiles, uint32_t cap, uint32_t cap_big, uint32_t* __restrict__ big_list) {
     // cap: what a finish workgroup of the usual shape holds; a bucket beyond it (up to cap_big) goes on big_list — word 0 the
     // count (zeroed by k4_hist), then the bucket numbers — for the large shape's launch; beyond cap_big, or more than
-    // CM4_MAX_BIG of them, the frame is handed back. (Two passes: cap == cap_big == 0xFFFF, no list: k4_idscan decides.)
+    // CM4_MAX_BIG of them, the frame is handed back. (Shared bins: cap == cap_big == what 2^shift finish workgroups hold, no
+    // list: a bin beyond that holds a bucket beyond one workgroup; k3_local<SUB> checks the buckets themselves.)
     __shared__ uint32_t s_lo[16][8], s_hi[16][8];
     if (st->status != CM_DEV_OK || st->outside) return;
     const uint32_t j = threadIdx.x & 7u, c = threadIdx.x >> 3;
@@ -374,7 +372,7 @@ __global__ __launch_bounds__(1024) void k4_colscan(CmFrameState* __restrict__ st
 // buckets in ascending address order with same-bucket records side by side, which is what lets the XCD's L2 put the
 // 32-byte runs of neighbouring tiles together (file header). Tiles are dealt to the XCDs in contiguous ranges.
 // ------------------------------------------------------------------------------------------------
-template <bool TWO, bool BALLOT>
+template <bool SUB, bool BALLOT>
 __global__ __launch_bounds__(CM2_BLOCK, 6) void k4_scatter(const CmFrameDev* __restrict__ fd, const CmTileDev* __restrict__ tiles,
                                                            CmFrameState* __restrict__ st, const uint16_t* __restrict__ bid,
                                                            const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ totals,
@@ -383,11 +381,10 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k4_scatter(const CmFrameDev* __r
                                                            uint32_t n_records, int fold, uint32_t* __restrict__ tile_kept,
                                                            unsigned char* __restrict__ dig_out, const uint32_t* __restrict__ big_list,
                                                            uint32_t sub_shift) {
-    // TWO: the bucket numbers have up to thirteen bits; this pass scatters by the low eleven and leaves the high ones as a
-    // byte beside every record (dig_out), for the second pass (k2_hist + k2_scatter<false>: cm_kernels_v2.hip) — or, shared
-    // bins (sub_shift != 0, cm_device.h), by all but the low sub_shift bits and leaves THOSE: which of its bin's buckets a
-    // record belongs to, for the finish (k3_local<SUB>).
-    auto bin_of = [&](uint32_t id) { return (TWO && sub_shift) ? id >> sub_shift : id & (CM4_BINS - 1); };
+    // SUB (shared bins, cm_device.h): the bucket numbers have up to thirteen bits; this pass scatters by all but the low
+    // sub_shift and leaves THOSE as a byte beside every record (dig_out): which of its bin's buckets a record belongs to, for
+    // the finish (k3_local<SUB>).
+    auto bin_of = [&](uint32_t id) { return SUB ? id >> sub_shift : id; };
     constexpr int HW = CM4_BINS / 2;                      // counter words per wave
     constexpr int STG = 2048;                             // staged records per round
     __shared__ uint32_t buf[STG * 4 + STG / 2];           // per-wave counters (8 x HW) | staging: records + buckets
@@ -438,7 +435,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k4_scatter(const CmFrameDev* __r
             rec[r].z = xf_row(m[8], m[9], m[10], m[11], p[r].x, p[r].y, p[r].z);
             rec[r].w = all_fields ? p[r].i : 0.f;
             vmask |= (bk[r] != 0xFFFFu) ? (1u << r) : 0u;
-            bk[r] &= TWO ? (CM4_MAX_BUCKETS - 1) : (CM4_BINS - 1);
+            bk[r] &= SUB ? (CM4_MAX_BUCKETS - 1) : (CM4_BINS - 1);
         }
     }
     __syncthreads();
@@ -528,7 +525,7 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k4_scatter(const CmFrameDev* __r
                 const uint32_t id = sbk[t - lo];
                 const uint32_t pos = gofs[bin_of(id)] + t;
                 rec_out[pos] = srec[t - lo];
-                if (TWO) dig_out[pos] = static_cast<unsigned char>(sub_shift ? id & ((1u << sub_shift) - 1u) : id >> 11);
+                if (SUB) dig_out[pos] = static_cast<unsigned char>(id & ((1u << sub_shift) - 1u));
             }
         }
     }
@@ -539,77 +536,14 @@ __global__ __launch_bounds__(CM2_BLOCK, 6) void k4_scatter(const CmFrameDev* __r
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Two passes: the finish tiles by bucket, so it needs where every bucket starts once BOTH passes have run. After the first
-// pass the records of low part `lo` sit at [bofs_lo[lo], bofs_lo[lo + 1]) with the high part of their bucket number as a
-// byte each: k4_idcount (one workgroup per low part) counts those bytes -> idtot[hi * 2048 + lo]; k4_idscan turns the
-// totals, in bucket order, into bofs (and refuses a bucket beyond the finish's capacity).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k4_idcount(const CmFrameState* __restrict__ st, const uint32_t* __restrict__ bofs_lo,
-                                                  const unsigned char* __restrict__ dig, uint32_t* __restrict__ idtot, uint32_t n_hi) {
-    __shared__ uint32_t cnt[CM4_MAX_BUCKETS / CM4_BINS];
-    if (st->status != CM_DEV_OK || st->outside || st->quant_abort) return;
-    const uint32_t lo = blockIdx.x;
-    if (threadIdx.x < CM4_MAX_BUCKETS / CM4_BINS) cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t a = bofs_lo[lo], e = bofs_lo[lo + 1];
-    uint32_t c[CM4_MAX_BUCKETS / CM4_BINS] = {0, 0, 0, 0};
-    for (uint32_t i = a + threadIdx.x; i < e; i += 256) {
-        const uint32_t h = dig[i];
-#pragma unroll
-        for (uint32_t q = 0; q < CM4_MAX_BUCKETS / CM4_BINS; ++q) c[q] += h == q ? 1u : 0u;
-    }
-#pragma unroll
-    for (uint32_t q = 0; q < CM4_MAX_BUCKETS / CM4_BINS; ++q) {
-        const uint32_t v = wave_sum_u32(c[q]);
-        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&cnt[q], v);
-    }
-    __syncthreads();
-    if (threadIdx.x < n_hi) idtot[threadIdx.x * CM4_BINS + lo] = cnt[threadIdx.x];
-}
-__global__ __launch_bounds__(1024) void k4_idscan(CmFrameState* __restrict__ st, uint32_t* __restrict__ host_state,
-                                                  const uint32_t* __restrict__ idtot, uint32_t* __restrict__ bofs, uint32_t n_ids,
-                                                  uint32_t cap) {
-    __shared__ uint32_t lds[16];
-    if (st->status != CM_DEV_OK || st->outside || st->quant_abort) return;
-    constexpr int PER = CM4_MAX_BUCKETS / 1024;
-    uint32_t v[PER], sum = 0;
-    bool big = false;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const uint32_t i = threadIdx.x * PER + k;
-        v[k] = i < n_ids ? idtot[i] : 0u;
-        big = big || v[k] > cap;
-        sum += v[k];
-    }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t incl = wave_incl_scan_u32(sum, lane);
-    if (lane == 63) lds[w] = incl;
-    __syncthreads();
-    uint32_t run = incl - sum;
-    for (int q = 0; q < w; ++q) run += lds[q];
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const uint32_t i = threadIdx.x * PER + k;
-        if (i <= n_ids) bofs[i] = run;                     // (i == n_ids: the total)
-        run += v[k];
-    }
-    if (big) {                                             // a bucket the finish cannot hold: the frame goes back
-        st->quant_abort = 1u;
-        host_state[offsetof(CmFrameState, err) / 4] = CM_DEV_ERR_QUANT;
-    }
-}
-
 }  // namespace
 
 void cmk4_hist(hipStream_t s, const CmFrameDev& f, CmFrameDev* fd, CmTileDev* tiles, bool do_setup, CmFrameState* st,
                const uint32_t* spl, uint32_t* cnt, uint16_t* bid, unsigned long long* tile_state, uint32_t n_tile_state, float* records,
-               int grid_mode, int check_box, uint32_t n_tiles, uint32_t n_buckets, uint32_t* grp_clear, uint32_t n_grp_clear,
-               uint32_t* big_list, uint32_t sub_shift) {
-    // sub_shift != 0: shared bins — counted per bucket >> sub_shift (<= CM4_BINS bins), one pass
-    const uint32_t np = (n_buckets > CM4_BINS && !sub_shift) ? 2u : 1u;
+               int grid_mode, int check_box, uint32_t n_tiles, uint32_t n_buckets, uint32_t* big_list, uint32_t sub_shift) {
+    // sub_shift (cm_quant_sub_shift(n_buckets)) != 0: shared bins — counted per bucket >> sub_shift (<= CM4_BINS bins)
 #define CM4_HIST(L) hipLaunchKernelGGL(k4_hist<L>, dim3(n_tiles), dim3(CM2_BLOCK), 0, s, f, fd, tiles, do_setup ? 1 : 0, st, spl, cnt, bid, \
-                                       tile_state, n_tile_state, records, grid_mode, check_box, grp_clear, n_grp_clear, np, big_list, sub_shift)
+                                       tile_state, n_tile_state, records, grid_mode, check_box, big_list, sub_shift)
     if (n_buckets <= 2048) CM4_HIST(11);
     else if (n_buckets <= 4096) CM4_HIST(12);
     else CM4_HIST(13);
@@ -626,16 +560,10 @@ void cmk4_scatter(hipStream_t s, const CmFrameDev* fd, const CmTileDev* tiles, C
                   const uint32_t* cnt, const uint32_t* totals, uint32_t* bofs, uint32_t n_buckets, void* rec_out,
                   const float* records, uint32_t n_records, int fold, uint32_t* tile_kept, uint32_t n_tiles, unsigned char* dig_out,
                   bool ballot, const uint32_t* big_list, uint32_t sub_shift) {
-#define CM4_SCATTER(TWO, BAL, DIG) hipLaunchKernelGGL((k4_scatter<TWO, BAL>), dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, bid, cnt, totals, \
+#define CM4_SCATTER(SUB, BAL, DIG) hipLaunchKernelGGL((k4_scatter<SUB, BAL>), dim3(n_tiles), dim3(CM2_BLOCK), 0, s, fd, tiles, st, bid, cnt, totals, \
                                                       bofs, n_buckets, reinterpret_cast<float4*>(rec_out), records, n_records, fold, tile_kept, DIG, big_list, \
                                                       sub_shift)
     if (dig_out) { if (ballot) CM4_SCATTER(true, true, dig_out); else CM4_SCATTER(true, false, dig_out); }
     else { if (ballot) CM4_SCATTER(false, true, nullptr); else CM4_SCATTER(false, false, nullptr); }
 #undef CM4_SCATTER
-}
-void cmk4_bucket_starts(hipStream_t s, CmFrameState* st, uint32_t* host_state, const uint32_t* bofs_lo, const unsigned char* dig,
-                        uint32_t* idtot, uint32_t* bofs, uint32_t n_buckets, uint32_t cap) {
-    const uint32_t n_hi = (n_buckets + CM4_BINS - 1) / CM4_BINS;
-    hipLaunchKernelGGL(k4_idcount, dim3(CM4_BINS), dim3(256), 0, s, st, bofs_lo, dig, idtot, n_hi);
-    hipLaunchKernelGGL(k4_idscan, dim3(1), dim3(1024), 0, s, st, host_state, idtot, bofs, n_hi * CM4_BINS, cap);
 }

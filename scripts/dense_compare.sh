@@ -1,13 +1,12 @@
 #!/bin/bash
-# usage: dense_compare.sh TAG — cfg3's dense variant (13.7 M records per frame) three ways in one GPU call (boxes differ by +-15 %):
-# the default route (one quantile pass over shared bins, cm_device.h cm_quant_sub_shift), CM_QUANT_SUB=0 (three fixed-grid passes),
-# CM_QUANT_SUB=0 CM_QUANT2=1 (two quantile passes); then rocprofv3 --kernel-trace --stats of the default route, one frame in flight.
+# usage: dense_compare.sh TAG — cfg3's dense variant (13.7 M records per frame) both ways in one GPU call (boxes differ by +-15 %):
+# the default route (one quantile pass over shared bins, cm_device.h cm_quant_sub_shift) and CM_QUANT_SUB=0 (three fixed-grid
+# passes), three frames in flight and one; rocprofv3 --kernel-trace --stats of the default route; the same on a moving stream.
 T=${1:-dense}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out
 B="--config 3 --dense --no-cpu-baseline --no-e2e"
 timeout -k 10 300 python3 bench.py $B > gpurun_out/${T}_dense_shared_bins.json 2> gpurun_out/${T}_dense.err || { tail -5 gpurun_out/${T}_dense.err; exit 1; }
 CM_QUANT_SUB=0 timeout -k 10 300 python3 bench.py $B > gpurun_out/${T}_dense_fixed_grid.json 2>> gpurun_out/${T}_dense.err || exit 1
-CM_QUANT_SUB=0 CM_QUANT2=1 timeout -k 10 300 python3 bench.py $B > gpurun_out/${T}_dense_two_passes.json 2>> gpurun_out/${T}_dense.err || exit 1
 timeout -k 10 300 python3 bench.py $B --inflight 1 > gpurun_out/${T}_dense_shared_bins_inflight1.json 2>> gpurun_out/${T}_dense.err || exit 1
 CM_QUANT_SUB=0 timeout -k 10 300 python3 bench.py $B --inflight 1 > gpurun_out/${T}_dense_fixed_grid_inflight1.json 2>> gpurun_out/${T}_dense.err || exit 1
 rm -rf gpurun_out/${T}_dense_prof
@@ -17,7 +16,7 @@ rm -rf gpurun_out/${T}_dense_prof
 python3 - $T <<'PY'
 import json, sys, csv
 t = sys.argv[1]
-for n in ("shared_bins", "fixed_grid", "two_passes", "shared_bins_inflight1", "fixed_grid_inflight1"):
+for n in ("shared_bins", "fixed_grid", "shared_bins_inflight1", "fixed_grid_inflight1"):
     d = json.loads(open(f"gpurun_out/{t}_dense_{n}.json").read().strip().splitlines()[-1])
     c = d["config"]
     print("%-24s ms/step %.4f  alone %.4f  quantile %s redone %s  parity %s" % (n, d["ms_per_step"], c.get("latency_one_frame_ms", {}).get("host_enqueue_to_result", 0),

@@ -7,6 +7,10 @@ cp gpurun_out/${T}_bench_static.json profiles/${R}_bench_static.json
 cp gpurun_out/${T}_bench_minpts0.json profiles/${R}_bench_minpts0.json
 cp gpurun_out/${T}_bench_cfg3.json profiles/${R}_bench_cfg3.json
 cp gpurun_out/${T}_bench_cfg3_dense.json profiles/${R}_bench_cfg3_dense.json
+[ -f gpurun_out/${T}_bench_steps20_warmup5.json ] && cp gpurun_out/${T}_bench_steps20_warmup5.json profiles/${R}_bench_steps20_warmup5.json
+for n in shared_bins fixed_grid shared_bins_inflight1 fixed_grid_inflight1 moving_shared_bins moving_fixed_grid; do
+  [ -f gpurun_out/${T}_dense_$n.json ] && cp gpurun_out/${T}_dense_$n.json profiles/${R}_cfg3_dense_$n.json
+done
 for n in cfg2_inflight1 cfg2_inflight3 cfg2_minpts0_inflight1 cfg3_inflight1 cfg3_dense_inflight1; do cp gpurun_out/${T}_${n}_kernel_stats.csv profiles/${R}_${n}_kernel_stats.csv; done
 cp gpurun_out/${T}_pmc_cfg2_minpts2_traffic.json profiles/${R}_pmc_traffic_cfg2_minpts2_bucket.json
 cp gpurun_out/${T}_pmc_cfg2_minpts0_traffic.json profiles/${R}_pmc_traffic_cfg2_minpts0_bucket.json

@@ -144,41 +144,23 @@ def test_switch_off(monkeypatch):
             assert not res.path_flags & QUANTILE
 
 
-def test_big_frame_takes_two_quantile_passes(monkeypatch):
-    """cfg3's dense variant at full size (8 x 2 M points, 86 % inside the ROI: 13.7 M records of a 29-bit index): more
-    buckets than the wide pass has bins — it scatters by the low eleven bits of the bucket number, a second, narrow pass
-    by the high ones: two global passes where the fixed grid takes three. CM_QUANT2=1: the variant is off by default (it
-    saves traffic, not time: cm_api.cpp enqueue)."""
-    monkeypatch.setenv("CM_QUANT2", "1")
-    sensors, params = synth.config3_dense(min_pts=2)
-    n = sum(s.n for s in sensors)
-    with capi.CloudMerger(max_points_total=n, max_sensors=len(sensors), flags=capi.FLAG_OCCUPANCY) as cm:
-        seen = []
-        for k in range(4):
-            res, rep = frame_against_oracle(cm, sensors, params, n)
-            needs_lds_rank(res)
-            seen.append((res.sort_passes, bool(res.path_flags & QUANTILE), bool(res.path_flags & REDONE)))
-        # (the first frame overflows a bucket of the two-pass fixed grid and is redone; the second takes three fixed-grid
-        # passes and leaves the splitters; from then on two quantile passes)
-        assert not seen[0][1] and seen[1][0] == 3 and not seen[1][1], seen
-        assert seen[2] == (2, True, False) and seen[3] == (2, True, False), seen
-
-
-@pytest.mark.parametrize("n_per_sensor,shift", [(1_000_000, 1), (2_000_000, 2)])
-def test_big_frame_takes_one_pass_over_shared_bins(n_per_sensor, shift):
+@pytest.mark.parametrize("n_per_sensor,shift,ballot", [(1_000_000, 1, False), (2_000_000, 2, False), (1_000_000, 1, True)])
+def test_big_frame_takes_one_pass_over_shared_bins(n_per_sensor, shift, ballot, monkeypatch):
     """cfg3's dense variant (8 x 1 M / 2 M points, 86 % inside the ROI: 6.9 M / 13.7 M records): more buckets of 1920 records
     than the pass has bins, so 2 / 4 neighbouring buckets share a bin and every finish workgroup picks its bucket's records
     out of the bin by their index (k3_local<SUB>, cm_device.h cm_quant_sub_shift) — still ONE global pass where the fixed
     grid takes three."""
-    from cloud_merger_amd import build
     assert shift == (1 if n_per_sensor == 1_000_000 else 2)
+    if ballot:
+        monkeypatch.setenv("CM_LDS_RANK", "0")           # (ranks by ballots in every kernel: what a device without lane-ordered LDS adds runs)
     sensors, params = synth.config3_dense(n_per_sensor=n_per_sensor, min_pts=2)
     n = sum(s.n for s in sensors)
     with capi.CloudMerger(max_points_total=n, max_sensors=len(sensors), flags=capi.FLAG_OCCUPANCY) as cm:
         seen = []
         for k in range(4):
             res, rep = frame_against_oracle(cm, sensors, params, n)
-            needs_lds_rank(res)
+            if not ballot:
+                needs_lds_rank(res)
             seen.append((res.sort_passes, bool(res.path_flags & QUANTILE), bool(res.path_flags & REDONE)))
         assert rep.n_merged > 2048 * 2600 * (1 if shift == 1 else 2), "more records than 2048 buckets hold"
         # (the fixed-grid frames in front leave the splitters — the very first may overflow a bucket and be redone with a pass
