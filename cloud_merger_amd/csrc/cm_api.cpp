@@ -600,8 +600,12 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
         const uint32_t nbins = (nb + (1u << sub) - 1u) >> sub;
         const uint32_t* spl = c->spl[c->spl_cur];
         uint32_t* spl_next = c->spl[c->spl_cur ^ 1];
+        // tile_info (one word pair per bucket) and, behind it, the group totals of the kept voxels: zeroed by k4_hist. The
+        // number of buckets comes from the LAST frame's size — a frame of a twentieth of its predecessor's points has fewer
+        // slots / 1024 than buckets (found by scripts/fuzz_shared_bins.py: the totals were then left as the last frame had them)
+        const uint32_t n_tile_state = std::max<uint32_t>(f.n_padded / 1024 + 2, nb + nb / 64 + 2);
         prof_mark(c, "k4_hist");
-        cmk4_hist(st, f, c->d_frame, c->d_tiles, do_setup_q, state, spl, c->qcnt, c->qbid, c->tile_state, f.n_padded / 1024 + 2, c->records,
+        cmk4_hist(st, f, c->d_frame, c->d_tiles, do_setup_q, state, spl, c->qcnt, c->qbid, c->tile_state, n_tile_state, c->records,
                   grid_mode, predicted ? 1 : 0, nt, nb, sub ? nullptr : c->qbig, sub);
         prof_mark(c, "k4_colscan");
         // The large finish shape (buckets of up to CM4_CAP_BIG records, one workgroup per CU) costs a launch of its own — 6 us on a
@@ -619,7 +623,7 @@ int launch_bucket(cm_ctx* c, int grid_mode, uint32_t n_global, uint32_t low_bits
         const void* rec_sorted = c->rec_a;
         void* stage = c->rec_b;
         const uint32_t* bofs = c->qbofs;
-        // (tile_info: one word pair per bucket; the group totals of the kept voxels behind them — nb + nb / 128 + 1 <= n_padded / 1024 + 2)
+        // (tile_info: one word pair per bucket; the group totals of the kept voxels behind them — n_tile_state words, see above)
         uint32_t* grp_cnt = reinterpret_cast<uint32_t*>(c->tile_state + nb);
         uint32_t* skey = c->out_key ? c->keys_a : nullptr;
         prof_mark(c, "k3_local");
@@ -886,6 +890,7 @@ int enqueue(cm_ctx* c, const cm_params* p, int mode = 0, const float* bounds = n
                 if (quant) {
                     const uint32_t nb = cm_quant_buckets(c->spl_n);
                     quant = nb != 0 && c->spl_n / nb <= CM4_MAX_AVG && est <= 2ull * c->spl_n + CM_TILE &&
+                            nb + nb / 64 + 2 <= c->cap_padded / 1024 + 2 &&      // (tile_info + group totals fit their array)
                             // Above 2048 buckets: still one pass, 2 or 4 neighbouring buckets to a bin (cm_device.h cm_quant_sub_shift;
                             // cfg3's dense variant, 13.7 M records: 0.38-0.41 against 0.46-0.50 ms per frame for three fixed-grid passes).
                             (nb <= CM4_BINS || c->quant_sub);

@@ -144,6 +144,23 @@ def test_switch_off(monkeypatch):
             assert not res.path_flags & QUANTILE
 
 
+def test_frame_of_a_twentieth_of_its_predecessors_points():
+    """The number of buckets comes from the LAST frame's size: a frame with far fewer points than its predecessor (same grid,
+    so it still takes the quantile pass) has fewer 1024-slot groups than buckets. Found by scripts/fuzz_shared_bins.py: the
+    per-bucket bookkeeping behind the last slot group was not zeroed (the kept voxels' group totals kept the last frame's)."""
+    sensors, params = synth.config2(n_per_sensor=1_000_000, min_pts=2)
+    small = [SensorCloud(data=sc.data[:50_000], n=50_000, q_xyzw=sc.q_xyzw, t_xyz=sc.t_xyz, point_step=sc.point_step,
+                         off_x=sc.off_x, off_y=sc.off_y, off_z=sc.off_z, off_i=sc.off_i) for sc in sensors]
+    n = sum(s.n for s in sensors)
+    with capi.CloudMerger(max_points_total=n, max_sensors=len(sensors), flags=capi.FLAG_OCCUPANCY) as cm:
+        seen = []
+        for fr in (sensors, sensors, small, small, sensors, small):
+            res, rep = frame_against_oracle(cm, fr, params, n)
+            needs_lds_rank(res)
+            seen.append(bool(res.path_flags & QUANTILE))
+        assert seen[1] and seen[2], seen          # (the small frame right behind the large one is the case)
+
+
 @pytest.mark.parametrize("n_per_sensor,shift,ballot", [(1_000_000, 1, False), (2_000_000, 2, False), (1_000_000, 1, True)])
 def test_big_frame_takes_one_pass_over_shared_bins(n_per_sensor, shift, ballot, monkeypatch):
     """cfg3's dense variant (8 x 1 M / 2 M points, 86 % inside the ROI: 6.9 M / 13.7 M records): more buckets of 1920 records
