@@ -1,7 +1,7 @@
 """Differential run of the quantile pass ABOVE 2048 buckets (shared bins: cm_device.h cm_quant_sub_shift, k3_local<SUB>) on one
 persistent context: cfg3's dense scene, every frame a different uniform subsample of each sensor's 2 M points (0.1 ... 2 M: the
 frame moves between 2048 buckets, two to a bin and four to a bin), poses drifting in the plane, now and then a jump in z (the
-index is z-major: the buckets no longer fit, the frame is handed back) or a tiny frame; min_points_per_voxel random. Every frame
+index is z-major: the buckets no longer fit, the frame is handed back) or a tiny frame; min_points_per_voxel and downsample_all_data random, now and then a sensor without points. Every frame
 against the oracle (occupancy bit-exact, centroids as tests/util.py).
 usage: python scripts/fuzz_shared_bins.py SECONDS [SEED]   -> gpurun_out/fuzz_shared_bins_SEED.log"""
 import os
@@ -47,9 +47,11 @@ with capi.CloudMerger(max_points_total=n_cap, max_sensors=len(base), flags=capi.
         yaw = float(rng.normal(0.0, 0.001))
         dq = np.array([0.0, 0.0, np.sin(yaw / 2), np.cos(yaw / 2)])
         params.min_points_per_voxel = int(rng.choice([0, 1, 2, 2, 3]))
+        params.downsample_all_data = bool(rng.random() < 0.8)
+        absent = int(rng.integers(0, len(base))) if rng.random() < 0.1 else -1     # now and then a sensor delivers an empty cloud
         sensors = []
-        for sc in base:
-            k = int(sc.n * size * rng.uniform(0.9, 1.0))
+        for i, sc in enumerate(base):
+            k = 0 if i == absent else int(sc.n * size * rng.uniform(0.9, 1.0))
             sensors.append(SensorCloud(data=sc.data[:k], n=k, q_xyzw=quat_mul(dq, np.asarray(sc.q_xyzw)),
                                        t_xyz=np.asarray(sc.t_xyz) + drift + np.array([0.0, 0.0, zoff]),
                                        point_step=sc.point_step, off_x=sc.off_x, off_y=sc.off_y, off_z=sc.off_z, off_i=sc.off_i))
