@@ -12,4 +12,5 @@ run 150 python3 scripts/fuzz_concurrent.py 100 11
 run 150 python3 scripts/fuzz_api.py 100 5
 run 150 python3 scripts/fuzz_fused.py 80 7
 run 300 python3 scripts/fuzz_shared_bins.py 200 1
+run 200 python3 scripts/fuzz_quantile_stream.py 120 1
 cat $O
