@@ -205,6 +205,30 @@ static void test_node_without_gpu_fails_loudly(bool expect_gpu) {
         CHECK(n2.on_cloud(1, cc) == CM_OK);                                // dropped: b already holds a fresh cloud (:356)
         CHECK(n2.spin_once() == CM_OK);
         CHECK(got_pts == 2 && got_stamp == 2500 && got_frame == "base_footprint");   // stamp of the newest FUSED cloud
+        // pipelined publish / deferred wait: the same frames come out, one and two calls later; flush() drains
+        for (int mode = 1; mode <= 2; ++mode) {
+            NodeConfig cp = c2;
+            cp.pipelined_publish = true;
+            cp.deferred_wait = mode == 2;
+            CloudMergerNode np(cp);
+            CHECK(np.ok());
+            np.set_transform(0, q, t); np.set_transform(1, q, t);
+            std::vector<size_t> pts; std::vector<uint64_t> stamps;
+            np.set_publisher([&](const std::string&, const PointCloud2& out) { pts.push_back(out.num_points()); stamps.push_back(out.header.stamp_ns); });
+            cm_result r{};
+            ca.header.stamp_ns = 1000; cb.header.stamp_ns = 2500;
+            CHECK(np.on_cloud(0, ca) == CM_OK && np.on_cloud(1, cb) == CM_OK);
+            CHECK(np.spin_once(&r) == CM_OK);                              // frame 1: fused (mode 1: waited for; mode 2: only enqueued)
+            CHECK(pts.empty() && r.n_out == (mode == 1 ? 2u : 0u));
+            CHECK(np.spin_once(&r) == CM_NOT_READY);                       // nothing new to fuse; mode 2: frame 1 is waited for now
+            CHECK(mode == 1 ? pts.size() == 1 : (pts.empty() && r.n_out == 2));
+            ca.header.stamp_ns = 5000; cc.header.stamp_ns = 7000;
+            CHECK(np.on_cloud(0, ca) == CM_OK && np.on_cloud(1, cc) == CM_OK);
+            CHECK(np.spin_once(&r) == CM_OK);                              // frame 2 (points a + c: two voxels again)
+            np.flush();
+            CHECK(pts.size() == 2 && pts[0] == 2 && pts[1] == 2 && stamps[0] == 2500 && stamps[1] == 7000 && np.frames_published() == 2);
+            if (pts.size() != 2) std::printf("  mode %d: %zu messages\n", mode, pts.size());
+        }
         // approximate time synchronisation: clouds 1 s apart are not fused; the older one is dropped
         NodeConfig c3 = c2;
         c3.max_stamp_spread_ns = 50ull * 1000 * 1000;                      // 50 ms

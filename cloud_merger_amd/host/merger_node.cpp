@@ -189,12 +189,27 @@ CloudMergerNode::~CloudMergerNode() {
     if (ctx_) cm_destroy(ctx_);
 }
 
-void CloudMergerNode::flush() {
+uint64_t CloudMergerNode::newest_stamp() const {
+    uint64_t newest = 0;
+    for (const auto& t : stamp_ns_) newest = std::max(newest, t.load());
+    return newest;
+}
+
+void CloudMergerNode::flush_published() {
     if (!pipe_in_flight_ || !ctx_) return;
     (void)cm_publish_wait(ctx_);
     pipe_in_flight_ = false;
     if (publish_) publish_(cfg_.voxel_topic, pipe_msg_[pipe_cur_ ^ 1]);
     frames_.fetch_add(1);
+}
+
+void CloudMergerNode::flush() {
+    if (frame_pending_ && ctx_) {                                       // deferred_wait: the frame enqueued by the last spin_once
+        flush_published();
+        frame_pending_ = false;
+        (void)collect_and_publish_async(nullptr);
+    }
+    flush_published();
 }
 
 // spin_once with NodeConfig::pipelined_publish: enqueue frame n; while it computes, finish and publish frame n - 1; wait
@@ -204,17 +219,50 @@ int CloudMergerNode::spin_once_pipelined(cm_result* res) {
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
     auto t0 = now();
+    const uint64_t stamp_enq = newest_stamp();                          // (of the clouds this fuse reads: a callback may deliver the next ones before the wait)
     const int eq = cm_merge_voxelize_async(ctx_, &cfg_.params);        // fusePointclouds + voxelgrid, enqueued
+    if (eq == CM_OK) enq_stamp_ = stamp_enq;
     const double t_enq = since(t0); t0 = now();
-    flush();                                                            // frame n - 1 goes out while frame n runs
-    const double t_flush = since(t0); t0 = now();
-    struct Report { bool on; double a, b; std::chrono::steady_clock::time_point t; double* w; double* p;
-                    ~Report() { if (on && (a > 3 || b > 3 || *w > 3 || *p > 3)) std::fprintf(stderr, "[node] slow tick: enqueue %.2f flush %.2f wait %.2f publish %.2f ms\n", a, b, *w, *p); } };
-    double t_wait = 0, t_pub = 0;
-    Report rep{trace, t_enq, t_flush, t0, &t_wait, &t_pub};
+    flush_published();                                                  // frame n - 1 goes out while frame n runs
+    const double t_flush = since(t0);
+    if (trace && (t_enq > 3 || t_flush > 3)) std::fprintf(stderr, "[node] slow tick: enqueue %.2f flush %.2f ms\n", t_enq, t_flush);
     if (res) *res = cm_result{};
     if (eq == CM_NOT_READY) return eq;                                  // :575 — nothing fused this tick
     if (eq < 0) { set_error(cm_last_error(ctx_)); return eq; }
+    return collect_and_publish_async(res);
+}
+
+// spin_once with NodeConfig::deferred_wait (on top of pipelined_publish): the frame enqueued by the LAST call is waited for and
+// its copy-out started, then this tick's frame is enqueued and the call returns without waiting for it — the kernels of frame
+// n run while the subscriber callbacks of tick n + 1 copy their clouds to the device (a sensor's submit goes to the buffer
+// the frame in flight does not read: cm_api.cpp Slot). The return value says whether THIS tick fused a frame (CM_OK /
+// CM_NOT_READY, as always); `res` is the PREVIOUS frame's result (zero when there was none to wait for).
+int CloudMergerNode::spin_once_deferred(cm_result* res) {
+    if (res) *res = cm_result{};
+    int st_prev = CM_OK;
+    if (frame_pending_) {
+        flush_published();                                              // frame n - 2 goes out
+        frame_pending_ = false;
+        st_prev = collect_and_publish_async(res);                       // frame n - 1: waited for, copy-out started
+        if (st_prev < 0) return st_prev;
+    }
+    const uint64_t stamp_enq = newest_stamp();
+    const int eq = cm_merge_voxelize_async(ctx_, &cfg_.params);        // frame n: enqueued, not waited for
+    if (eq == CM_OK) { frame_pending_ = true; enq_stamp_ = stamp_enq; }
+    else if (eq != CM_NOT_READY) { set_error(cm_last_error(ctx_)); return eq; }
+    return eq;                                                          // CM_OK: a frame was fused this tick; CM_NOT_READY: none (:575)
+}
+
+// The frame in flight on the context: cm_wait, the consumed generations, its message, the start of its copy-out.
+int CloudMergerNode::collect_and_publish_async(cm_result* res) {
+    static const bool trace = std::getenv("CM_NODE_TRACE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
+    auto t0 = now();
+    struct Report { bool on; double* w; double* p;
+                    ~Report() { if (on && (*w > 3 || *p > 3)) std::fprintf(stderr, "[node] slow tick: wait %.2f publish %.2f ms\n", *w, *p); } };
+    double t_wait = 0, t_pub = 0;
+    Report rep{trace, &t_wait, &t_pub};
     cm_result r{};
     const int st = cm_wait(ctx_, &r);
     t_wait = since(t0); t0 = now();
@@ -249,9 +297,7 @@ int CloudMergerNode::spin_once_pipelined(cm_result* res) {
         if (cs != CM_OK) { set_error(cm_last_error(ctx_)); return cs; }
     }
     msg.header.seq = seq_++;
-    uint64_t newest = 0;
-    for (const auto& t : stamp_ns_) newest = std::max(newest, t.load());
-    msg.header.stamp_ns = (cfg_.stamp_from_inputs && newest) ? newest : clock_();
+    msg.header.stamp_ns = (cfg_.stamp_from_inputs && enq_stamp_) ? enq_stamp_ : clock_();
     msg.header.frame_id = cfg_.base_frame;
     pipe_in_flight_ = true;
     pipe_cur_ ^= 1;
@@ -316,7 +362,7 @@ int CloudMergerNode::spin_once(cm_result* res) {
             return CM_NOT_READY;
         }
     }
-    if (cfg_.pipelined_publish && !cfg_.ground_enable) return spin_once_pipelined(res);
+    if (cfg_.pipelined_publish && !cfg_.ground_enable) return (cfg_.deferred_wait && !cfg_.max_stamp_spread_ns) ? spin_once_deferred(res) : spin_once_pipelined(res);   // (the stamp gate above reads what the last frame consumed: known only once it was waited for)
     cm_result r{};
     const int st = cm_merge_voxelize(ctx_, &cfg_.params, &r);      // fusePointclouds + voxelgrid
     if (res) *res = r;

@@ -40,6 +40,11 @@ struct NodeConfig {
     // voxel cloud reaches its subscribers one tick later, the loop no longer waits for PCIe (flush() publishes the last
     // one). Off by default: the reference publishes within the tick (:574-577). Not with ground_enable (three clouds per tick).
     bool pipelined_publish = false;
+    // deferred_wait (needs pipelined_publish): spin_once enqueues this tick's frame and returns; the NEXT call waits for it. The
+    // frame's kernels then run while the next tick's callbacks copy their clouds to the device — for replays and bulk
+    // conversion, where frames per second count; a live 10 Hz node gains nothing and loses a tick of latency. spin_once's
+    // return value still says whether THIS tick fused a frame; its cm_result is the previous frame's.
+    bool deferred_wait = false;
     // Stamp of the published cloud. false: ros::Time::now() at publish like the reference (:217).
     // true: the newest stamp among the fused input clouds — what pcl::PointCloud::operator+= leaves in
     // the fused cloud's header and what §8f rank 4 proposes.
@@ -117,7 +122,7 @@ public:
     // while(ros::ok()) { spin_once(); loop_rate.sleep(); } (:549-584)
     void run(const std::atomic<bool>& stop);
     // pipelined_publish: publishes the frame whose copy-out is still in flight (end of a replay, shutdown)
-    void flush();
+    void flush();                                   // (deferred_wait: also the frame that was enqueued and not yet waited for)
 
     uint64_t frames_published() const { return frames_; }
     // how the fused frames were computed (cm_result.path_flags): on the one-pass quantile route / handed back and redone
@@ -142,6 +147,12 @@ private:
     void* pipe_registered_[2] = {nullptr, nullptr}; // ... their payload buffers, made DMA-able once (cm_host_register)
     int pipe_cur_ = 0;
     bool pipe_in_flight_ = false;
+    bool frame_pending_ = false;                    // deferred_wait: a frame is enqueued on the context and not yet waited for
+    uint64_t enq_stamp_ = 0;                        // pipelined modes: newest input stamp when the frame in flight was enqueued
+    uint64_t newest_stamp() const;
+    void flush_published();
+    int spin_once_deferred(cm_result* res);
+    int collect_and_publish_async(cm_result* res);
     int spin_once_pipelined(cm_result* res);
     std::vector<std::atomic<uint64_t>> stamp_ns_;   // stamp of the cloud each sensor slot currently holds
     // A slot holds a cloud no fuse has consumed yet when more submits were accepted for it than the last fuse had seen

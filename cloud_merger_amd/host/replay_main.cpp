@@ -6,7 +6,7 @@
 //   cloudmerge_replay --dir SEQ --sensors 4 --frames 100 [--config NODE.cfg] [--leaf 0.05] [--min-pts 2]
 //                     [--crop x0 y0 z0 x1 y1 z1] [--outlier RADIUS MIN_NEIGHBOURS] [--out OUTDIR]
 //                     [--device 0] [--shard 0/1]
-//                     [--rate 10 --realtime] [--threads]
+//                     [--rate 10 --realtime] [--threads] [--pipeline | --defer] [--pin]
 // --threads: the reference's threading — one subscriber thread per sensor (ros::AsyncSpinner(6), :513) hands the clouds to
 //   the node while the main thread runs the loop body (:570-580). A sensor's thread offers its next cloud again until the
 //   slot has been consumed (lossless, unlike the live node, which drops: :330), so frame k is made of every sensor's
@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
     std::string dir, out_dir;
     int n_sensors = 4, n_frames = 1, device = 0, rank = 0, world = 1;
     double rate = 10.0;
-    bool realtime = false, have_config = false, threads = false;
+    bool realtime = false, have_config = false, threads = false, pin = false;
     int repeat = 1;
     NodeConfig cfg;
     cfg.params.leaf[0] = cfg.params.leaf[1] = cfg.params.leaf[2] = 0.05f;
@@ -55,11 +55,13 @@ int main(int argc, char** argv) {
         else if (k == "--rate") rate = std::atof(next());
         else if (k == "--realtime") realtime = true;
         else if (k == "--threads") threads = true;
+        else if (k == "--pin") pin = true;                          // one thread: the clouds' host buffers are made DMA-able once (cm_host_register)
         else if (k == "--pipeline") cfg.pipelined_publish = true;   // publish frame n - 1 while frame n computes (merger_node.hpp)
+        else if (k == "--defer") cfg.pipelined_publish = cfg.deferred_wait = true;   // ... and wait for frame n during tick n + 1: its kernels run beside that tick's host-to-device copies
         else if (k == "--live") {                                  // the live node's own configuration (pc_preprocessing_main.cpp): six sensors,
-            const bool pp = cfg.pipelined_publish;                  // ROI, 10 cm, min 2 points, zone-wise ground removal + per-slab outlier filter
+            const bool pp = cfg.pipelined_publish, dw = cfg.deferred_wait;                  // ROI, 10 cm, min 2 points, zone-wise ground removal + per-slab outlier filter
             cfg = live_node_config();
-            cfg.pipelined_publish = pp;
+            cfg.pipelined_publish = pp; cfg.deferred_wait = dw;
             n_sensors = static_cast<int>(cfg.sensors.size());
             have_config = true;
         }
@@ -139,6 +141,8 @@ int main(int argc, char** argv) {
             for (int s = 0; s < n_sensors; ++s) {
                 if (!read_pcd(frame_path(my_frames[i], s), &all[i][s], &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
                 points += all[i][s].num_points();
+                // --pin: the payloads become DMA-able (what a transport that receives into registered buffers delivers)
+                if (pin && !all[i][s].data.empty()) (void)cm_host_register(all[i][s].data.data(), all[i][s].data.size());
             }
         std::atomic<bool> failed{false};
         // (set once the loop thread has fused its frames: a sensor the gate does not wait for — the reference's top_middle —
@@ -178,6 +182,7 @@ int main(int argc, char** argv) {
         if (failed.load()) return 1;
         node.flush();
         const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (pin) for (auto& fr : all) for (auto& m : fr) if (!m.data.empty()) (void)cm_host_unregister(m.data.data());
         const int timed = done - static_cast<int>(n_warm);
         const uint64_t pts_timed = points * static_cast<uint64_t>(repeat > 1 ? repeat - 1 : 1);
         std::printf("{\"rank\": %d, \"world\": %d, \"frames\": %d, \"points_in\": %llu, \"voxels_out\": %llu, "
@@ -185,7 +190,8 @@ int main(int argc, char** argv) {
                     "\"mode\": \"subscriber threads (%d) + loop thread%s\", \"warmup_frames\": %d, "
                     "\"quantile_frames\": %llu, \"redone_frames\": %llu}\n",
                     rank, world, timed, static_cast<unsigned long long>(pts_timed), static_cast<unsigned long long>(voxels - voxels_warm),
-                    wall, wall, timed / wall, pts_timed / wall, n_sensors, cfg.pipelined_publish ? ", pipelined publish" : "",
+                    wall, wall, timed / wall, pts_timed / wall, n_sensors,
+                    (std::string(cfg.deferred_wait ? ", pipelined publish, deferred wait" : cfg.pipelined_publish ? ", pipelined publish" : "") + (pin ? ", pinned inputs" : "")).c_str(),
                     static_cast<int>(n_warm), static_cast<unsigned long long>(node.frames_quantile()),
                     static_cast<unsigned long long>(node.frames_redone()));
         return 0;
@@ -197,12 +203,21 @@ int main(int argc, char** argv) {
     std::vector<double> tick_ms;                               // callbacks + loop body of every tick (host buffers in, message out)
     double t_steady = 0, slowest_ms = 0;
     int slowest_tick = -1;
+    std::vector<void*> pinned(n_sensors, nullptr);             // --pin: what is registered of every sensor's buffer
+    std::vector<size_t> pinned_cap(n_sensors, 0);
     for (int f = rank; f < n_frames; f += world) {
         cur_frame = f;
         for (int s = 0; s < n_sensors; ++s) {
             if (f != rank || clouds[s].data.empty())
                 if (!read_pcd(frame_path(f, s), &clouds[s], &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
             points += clouds[s].num_points();
+            if (pin && !clouds[s].data.empty() && (clouds[s].data.data() != pinned[s] || clouds[s].data.capacity() > pinned_cap[s])) {
+                if (pinned[s]) (void)cm_host_unregister(pinned[s]);  // (a sequence's clouds have one size: registered once in practice)
+                pinned[s] = nullptr;
+                if (cm_host_register(clouds[s].data.data(), clouds[s].data.capacity()) == CM_OK) {
+                    pinned[s] = clouds[s].data.data(); pinned_cap[s] = clouds[s].data.capacity();
+                }
+            }
         }
         const auto g0 = std::chrono::steady_clock::now();
         for (int s = 0; s < n_sensors; ++s) {
@@ -221,6 +236,7 @@ int main(int argc, char** argv) {
         if (realtime) std::this_thread::sleep_until(t0 + std::chrono::duration<double>(done / rate));
     }
     node.flush();
+    for (void* p : pinned) if (p) (void)cm_host_unregister(p);
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::sort(tick_ms.begin(), tick_ms.end());
     const double p50 = tick_ms.empty() ? 0.0 : tick_ms[tick_ms.size() / 2];
@@ -231,7 +247,8 @@ int main(int argc, char** argv) {
                 "\"mode\": \"one thread: callbacks, fuse, publish%s\", \"quantile_frames\": %llu, \"redone_frames\": %llu}\n",
                 rank, world, done, static_cast<unsigned long long>(points), static_cast<unsigned long long>(voxels), wall,
                 t_gpu, done / t_gpu, points / t_gpu, p50, p99, slowest_tick, tick_ms.empty() ? 0.0 : tick_ms.size() / t_steady,
-                cfg.pipelined_publish ? " (pipelined)" : "", static_cast<unsigned long long>(node.frames_quantile()),
+                cfg.deferred_wait ? (pin ? " (pipelined, deferred wait, pinned inputs)" : " (pipelined, deferred wait)")
+                                  : cfg.pipelined_publish ? (pin ? " (pipelined, pinned inputs)" : " (pipelined)") : (pin ? " (pinned inputs)" : ""), static_cast<unsigned long long>(node.frames_quantile()),
                 static_cast<unsigned long long>(node.frames_redone()));
     return 0;
 }

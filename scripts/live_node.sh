@@ -2,7 +2,7 @@
 # Small frames / the live node: cfg4's shape (4 sensors x 120 k points) and the reference node's own
 # configuration (--live: six sensors, ROI, 10 cm, min 2 points, zone-wise ground removal + per-slab outlier filter) through
 # cloudmerge_replay from host .pcd payloads: one thread (tick latency p50 / p99), subscriber threads, subscriber threads +
-# pipelined publish. usage: live_node.sh TAG   -> gpurun_out/TAG_live_node.jsonl, TAG_live_node_kernels.txt
+# pipelined publish, the deferred wait on top of it (--defer: frame n waited for during tick n + 1), DMA-able input buffers (--pin). usage: live_node.sh TAG   -> gpurun_out/TAG_live_node.jsonl, TAG_live_node_kernels.txt
 TAG=${1:-live}
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -17,16 +17,22 @@ run() { echo "# $*" >> $OUT; for rep in 1 2 3; do timeout -k 5 60 "$@" >> $OUT; 
 CROP="--crop -15 -5 -0.5 60 5 3"
 run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.1 --min-pts 2 $CROP
 run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.1 --min-pts 2 $CROP --pipeline
+run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.1 --min-pts 2 $CROP --pipeline --pin
+run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.1 --min-pts 2 $CROP --defer
+run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.1 --min-pts 2 $CROP --defer --pin
 run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.1 --min-pts 2 $CROP --threads --repeat 4
 run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.1 --min-pts 2 $CROP --threads --repeat 4 --pipeline
+run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.1 --min-pts 2 $CROP --threads --repeat 4 --defer --pin
 run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.05 --min-pts 2 --threads --repeat 4
 run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.05 --min-pts 2 --threads --repeat 4 --pipeline
+run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.05 --min-pts 2 --threads --repeat 4 --defer --pin
+run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.05 --min-pts 2 --defer --pin
 run $R --dir $SEQ6 --live --frames 60
 run $R --dir $SEQ6 --live --frames 60 --threads --repeat 4
 grep -v "^#" $OUT | python3 -c "
 import json,sys
 for l in sys.stdin:
-    d=json.loads(l); print('%-60s %8.0f frames/s  tick p50 %s p99 %s' % (d.get('mode','')[:60], d.get('steady_frames_per_s', d['frames_per_s']), d.get('tick_ms_p50','-'), d.get('tick_ms_p99','-')))
+    d=json.loads(l); print('%-92s %8.0f frames/s  tick p50 %s p99 %s' % (d.get('mode','')[:92], d.get('steady_frames_per_s', d['frames_per_s']), d.get('tick_ms_p50','-'), d.get('tick_ms_p99','-')))
 "
 # kernels per tick of the live configuration
 rm -rf gpurun_out/${TAG}_live_prof
