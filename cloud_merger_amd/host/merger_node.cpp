@@ -331,7 +331,7 @@ int CloudMergerNode::on_cloud(size_t sensor, const PointCloud2& msg, bool* accep
     const XyziLayout l = find_xyzi(msg);
     if (!l.ok) { set_error(l.error); return CM_BAD_ARG; }
     std::lock_guard<std::mutex> lk(slot_mu_[sensor]);
-    const int st = cm_submit_cloud(ctx_, static_cast<uint32_t>(sensor), msg.data.data(),
+    const int st = (cfg_.async_submit ? cm_submit_cloud_async : cm_submit_cloud)(ctx_, static_cast<uint32_t>(sensor), msg.data.data(),
                                    static_cast<uint32_t>(msg.num_points()), msg.point_step, l.off_x, l.off_y, l.off_z, l.off_i);
     if (st == CM_OK) { stamp_ns_[sensor].store(msg.header.stamp_ns); submitted_[sensor].fetch_add(1); }   // CM_SKIPPED: the slot keeps its older cloud
     if (accepted) *accepted = st == CM_OK;

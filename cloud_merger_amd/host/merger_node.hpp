@@ -45,6 +45,11 @@ struct NodeConfig {
     // conversion, where frames per second count; a live 10 Hz node gains nothing and loses a tick of latency. spin_once's
     // return value still says whether THIS tick fused a frame; its cm_result is the previous frame's.
     bool deferred_wait = false;
+    // async_submit: on_cloud returns behind the ENQUEUE of the host-to-device copy (cm_submit_cloud_async); the frame that
+    // fuses the cloud waits for the copy on the device. The message's payload must then stay valid and unchanged until that
+    // frame has been waited for — a transport that keeps its receive buffers (and registers them: cm_host_register) can say
+    // so; a callback whose message dies when it returns cannot.
+    bool async_submit = false;
     // Stamp of the published cloud. false: ros::Time::now() at publish like the reference (:217).
     // true: the newest stamp among the fused input clouds — what pcl::PointCloud::operator+= leaves in
     // the fused cloud's header and what §8f rank 4 proposes.

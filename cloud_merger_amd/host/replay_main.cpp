@@ -6,7 +6,7 @@
 //   cloudmerge_replay --dir SEQ --sensors 4 --frames 100 [--config NODE.cfg] [--leaf 0.05] [--min-pts 2]
 //                     [--crop x0 y0 z0 x1 y1 z1] [--outlier RADIUS MIN_NEIGHBOURS] [--out OUTDIR]
 //                     [--device 0] [--shard 0/1]
-//                     [--rate 10 --realtime] [--threads] [--pipeline | --defer] [--pin]
+//                     [--rate 10 --realtime] [--threads] [--pipeline | --defer] [--pin] [--async]
 // --threads: the reference's threading — one subscriber thread per sensor (ros::AsyncSpinner(6), :513) hands the clouds to
 //   the node while the main thread runs the loop body (:570-580). A sensor's thread offers its next cloud again until the
 //   slot has been consumed (lossless, unlike the live node, which drops: :330), so frame k is made of every sensor's
@@ -55,13 +55,14 @@ int main(int argc, char** argv) {
         else if (k == "--rate") rate = std::atof(next());
         else if (k == "--realtime") realtime = true;
         else if (k == "--threads") threads = true;
+        else if (k == "--async") cfg.async_submit = true;           // --threads only (the preloaded clouds never change): on_cloud does not wait for its copy
         else if (k == "--pin") pin = true;                          // one thread: the clouds' host buffers are made DMA-able once (cm_host_register)
         else if (k == "--pipeline") cfg.pipelined_publish = true;   // publish frame n - 1 while frame n computes (merger_node.hpp)
         else if (k == "--defer") cfg.pipelined_publish = cfg.deferred_wait = true;   // ... and wait for frame n during tick n + 1: its kernels run beside that tick's host-to-device copies
         else if (k == "--live") {                                  // the live node's own configuration (pc_preprocessing_main.cpp): six sensors,
-            const bool pp = cfg.pipelined_publish, dw = cfg.deferred_wait;                  // ROI, 10 cm, min 2 points, zone-wise ground removal + per-slab outlier filter
+            const bool pp = cfg.pipelined_publish, dw = cfg.deferred_wait, as = cfg.async_submit;                  // ROI, 10 cm, min 2 points, zone-wise ground removal + per-slab outlier filter
             cfg = live_node_config();
-            cfg.pipelined_publish = pp; cfg.deferred_wait = dw;
+            cfg.pipelined_publish = pp; cfg.deferred_wait = dw; cfg.async_submit = as;
             n_sensors = static_cast<int>(cfg.sensors.size());
             have_config = true;
         }
@@ -104,6 +105,7 @@ int main(int argc, char** argv) {
     }
     cfg.max_points_total = first_total + first_total / 2 + 1024;
 
+    if (!threads) cfg.async_submit = false;                    // (one thread: the next frame is read into the same buffers)
     CloudMergerNode node(cfg);
     if (!node.ok()) { std::fprintf(stderr, "node: %s\n", node.error().c_str()); return 1; }
     {
@@ -115,6 +117,8 @@ int main(int argc, char** argv) {
         }
     }
     uint64_t voxels = 0, points = 0;
+    uint64_t voxels_warm = 0;                                  // --threads --repeat: voxels of the warm-up pass's frames (not timed)
+    size_t n_published = 0, n_warm_frames = 0;
     int cur_frame = 0;
     // frames handed to spin_once whose voxel cloud has not been published yet, oldest first (with --pipeline a frame is
     // published during the NEXT spin_once, or by flush())
@@ -122,6 +126,7 @@ int main(int argc, char** argv) {
     node.set_publisher([&](const std::string& topic, const PointCloud2& msg) {
         if (topic != cfg.voxel_topic) return;                  // (--live also publishes the no-ground and ground clouds)
         voxels += msg.num_points();
+        if (++n_published == n_warm_frames) voxels_warm = voxels;   // (published frames, not fused ones: the pipelined modes publish one or two ticks late)
         const int pub_frame = unpublished.empty() ? cur_frame : unpublished.front();
         if (!unpublished.empty()) unpublished.pop_front();
         if (!out_dir.empty()) {
@@ -150,6 +155,7 @@ int main(int argc, char** argv) {
         std::atomic<bool> loop_done{false};
         const size_t n_play = all.size() * static_cast<size_t>(repeat);
         const size_t n_warm = repeat > 1 ? all.size() : 0;
+        n_warm_frames = n_warm;
         auto t0 = std::chrono::steady_clock::now();
         std::vector<std::thread> subs;
         for (int s = 0; s < n_sensors; ++s)
@@ -165,9 +171,8 @@ int main(int argc, char** argv) {
                 }
             });
         int done = 0;
-        uint64_t voxels_warm = 0;
         while (done < static_cast<int>(n_play) && !failed.load()) {
-            if (static_cast<size_t>(done) == n_warm && n_warm) { t0 = std::chrono::steady_clock::now(); voxels_warm = voxels; }
+            if (static_cast<size_t>(done) == n_warm && n_warm) t0 = std::chrono::steady_clock::now();
             cur_frame = my_frames[static_cast<size_t>(done) % all.size()];
             cm_result r{};
             unpublished.push_back(cur_frame);
@@ -191,7 +196,7 @@ int main(int argc, char** argv) {
                     "\"quantile_frames\": %llu, \"redone_frames\": %llu}\n",
                     rank, world, timed, static_cast<unsigned long long>(pts_timed), static_cast<unsigned long long>(voxels - voxels_warm),
                     wall, wall, timed / wall, pts_timed / wall, n_sensors,
-                    (std::string(cfg.deferred_wait ? ", pipelined publish, deferred wait" : cfg.pipelined_publish ? ", pipelined publish" : "") + (pin ? ", pinned inputs" : "")).c_str(),
+                    (std::string(cfg.deferred_wait ? ", pipelined publish, deferred wait" : cfg.pipelined_publish ? ", pipelined publish" : "") + (pin ? ", pinned inputs" : "") + (cfg.async_submit ? ", asynchronous submits" : "")).c_str(),
                     static_cast<int>(n_warm), static_cast<unsigned long long>(node.frames_quantile()),
                     static_cast<unsigned long long>(node.frames_redone()));
         return 0;

@@ -2,7 +2,7 @@
 # Small frames / the live node: cfg4's shape (4 sensors x 120 k points) and the reference node's own
 # configuration (--live: six sensors, ROI, 10 cm, min 2 points, zone-wise ground removal + per-slab outlier filter) through
 # cloudmerge_replay from host .pcd payloads: one thread (tick latency p50 / p99), subscriber threads, subscriber threads +
-# pipelined publish, the deferred wait on top of it (--defer: frame n waited for during tick n + 1), DMA-able input buffers (--pin). usage: live_node.sh TAG   -> gpurun_out/TAG_live_node.jsonl, TAG_live_node_kernels.txt
+# pipelined publish, the deferred wait on top of it (--defer: frame n waited for during tick n + 1), DMA-able input buffers (--pin), submits that do not wait for their copy (--async). usage: live_node.sh TAG   -> gpurun_out/TAG_live_node.jsonl, TAG_live_node_kernels.txt
 TAG=${1:-live}
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -22,10 +22,11 @@ run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.1 --min-pts 2 $CROP --defer
 run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.1 --min-pts 2 $CROP --defer --pin
 run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.1 --min-pts 2 $CROP --threads --repeat 4
 run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.1 --min-pts 2 $CROP --threads --repeat 4 --pipeline
-run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.1 --min-pts 2 $CROP --threads --repeat 4 --defer --pin
+run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.1 --min-pts 2 $CROP --threads --repeat 4 --pipeline --pin --async
+run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.1 --min-pts 2 $CROP --threads --repeat 4 --defer --pin --async
 run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.05 --min-pts 2 --threads --repeat 4
 run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.05 --min-pts 2 --threads --repeat 4 --pipeline
-run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.05 --min-pts 2 --threads --repeat 4 --defer --pin
+run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.05 --min-pts 2 --threads --repeat 4 --defer --pin --async
 run $R --dir $SEQ4 --sensors 4 --frames 100 --leaf 0.05 --min-pts 2 --defer --pin
 run $R --dir $SEQ6 --live --frames 60
 run $R --dir $SEQ6 --live --frames 60 --threads --repeat 4

@@ -47,14 +47,16 @@ def test_host_unit_tests_gpu(host_bins, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("threads", [False, True, "pipeline", "threads+pipeline", "defer", "defer+pin", "threads+defer+pin"])
+@pytest.mark.parametrize("threads", [False, True, "pipeline", "threads+pipeline", "defer", "defer+pin", "threads+defer+pin", "threads+defer+pin+async"])
 def test_replay_sequence_matches_oracle(host_bins, tmp_path, threads):
     """threads: subscriber threads beside the loop thread; pipeline: NodeConfig::pipelined_publish — frame n - 1 is
     published (cm_result_publish_async into a registered message buffer) while frame n computes; defer: NodeConfig::deferred_wait on
     top of it — frame n is only waited for during tick n + 1, beside that tick's host-to-device copies; pin: the clouds' host
-    buffers registered for DMA (cm_host_register); same clouds every way."""
+    buffers registered for DMA (cm_host_register); async: the subscriber threads' submits do not wait for their copies
+    (cm_submit_cloud_async); same clouds every way."""
     flags = {False: [], True: ["--threads"], "pipeline": ["--pipeline"], "threads+pipeline": ["--threads", "--pipeline"],
-             "defer": ["--defer"], "defer+pin": ["--defer", "--pin"], "threads+defer+pin": ["--threads", "--defer", "--pin"]}[threads]
+             "defer": ["--defer"], "defer+pin": ["--defer", "--pin"], "threads+defer+pin": ["--threads", "--defer", "--pin"],
+             "threads+defer+pin+async": ["--threads", "--defer", "--pin", "--async"]}[threads]
     from oracle import oracle
     from tests.util import assert_centroids_close, xyzi_of
 
