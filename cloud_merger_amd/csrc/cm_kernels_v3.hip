@@ -119,7 +119,10 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
     // [bofs[t], bofs[t+1]) with indices in [spl[t], spl[t+1]): no bucket boundaries to look for, no tail to follow.
     // spl_next: where the next frame's splitters go (every tile writes the quantiles that fall into its sorted range).
     constexpr int LWAVES = LBLOCK / 64, LITEMS = (LCAP + LBLOCK - 1) / LBLOCK, EXT0 = LBLOCK < 256 ? LBLOCK : 256;
-    constexpr int BINS = 1024, HWORDS = BINS / 2;          // two 16-bit counters per LDS word
+    // (SUB: 9-bit digits — with the slots' places (sp) beside them 1024 counters per wave would leave room for three
+    // workgroups per CU instead of four)
+    constexpr int WB = SUB ? 9 : 10, BINS = 1 << WB, HWORDS = BINS / 2;          // two 16-bit counters per LDS word
+    constexpr uint32_t MAXJ = LWAVES * HWORDS * 4 / sizeof(Job3);                  // jobs that fit where the counters were
     static_assert(LT == 4 * LBLOCK && LCAP <= 0x7FFE && HWORDS <= LBLOCK && LWAVES * HWORDS * 2 >= LCAP, "tile geometry");
     __shared__ uint32_t sk[LCAP];                      // key of every slot
     __shared__ uint16_t si[LCAP];                      // slots in sorted order
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
         const unsigned long long span = QUANT ? static_cast<unsigned long long>(q_hi - q_lo)
                                               : static_cast<unsigned long long>(h_last - h_first + 1u) << L;
         const uint32_t nb = span > 1ull ? 64u - static_cast<uint32_t>(__builtin_clzll(span - 1ull)) : 0u;
-        const uint32_t npass = nb ? (nb + 9u) / 10u : 1u;
+        const uint32_t npass = nb ? (nb + WB - 1u) / WB : 1u;
         const uint32_t width = nb ? (nb + npass - 1u) / npass : 0u;
         const uint32_t dmask = (1u << width) - 1u;
         const uint32_t rounds = (m + LBLOCK - 1) / LBLOCK;
@@ -538,7 +541,8 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
                 const uint32_t jn = atomicAdd(&s_njobs, 1u);
                 Job3 jb;
                 jb.p = p; jb.key = ckey; jb.kid = kid++; jb.cnt = cn; jb.sx = sx; jb.sy = sy; jb.sz = sz; jb.sw = sw;
-                jobs[jn] = jb;
+                if (MAXJ >= static_cast<uint32_t>(LBLOCK) || jn < MAXJ) jobs[jn] = jb;
+                else host_state[offsetof(CmFrameState, err) / 4] = CM_DEV_ERR_BUCKET;    // (more long voxels than job slots: the frame is handed back)
             } else {
                 emit(kid++, ckey, sx, sy, sz, sw, cn);
             }
@@ -553,7 +557,7 @@ __global__ __launch_bounds__(LBLOCK, WPS) void k3_local(const CmFrameDev* __rest
         // points, and the tiles behind it have nothing of their own to do) all waves share every job — wave w takes the
         // steps w, w + LWAVES, ... of it — and their partial sums are added in wave order.
         __syncthreads();
-        const uint32_t njobs = SCAL(s_njobs);
+        const uint32_t njobs = min(SCAL(s_njobs), MAXJ);
         const bool coop = !(njobs >= static_cast<uint32_t>(LWAVES) || m < 512u * max(c_t, 1u));   // (uniform)
         Job3* part = jobs + 64;                                // (coop: fewer than LWAVES jobs — room for the waves' partial sums)
         // one chunk: the 64 positions from p on that belong to the run of jkey (in: which lanes hold one of its records)
@@ -751,7 +755,7 @@ void cmk3_local(hipStream_t s, const CmFrameDev* fd, CmFrameState* st, uint32_t*
     // ballot: the LDS sort ranks by ballots instead of returning adds (cm_common.hpp wave_rank_ballot).
     static_assert(CM4_CAP == 4032, "k4_colscan's capacity check is this kernel's LCAP");
     // sub_shift != 0 (shared bins): 2^sub_shift buckets per bin, the workgroups of a bin side by side on one XCD — eight bins
-    // (one per XCD) times 2^sub_shift workgroups per step of the grid; 48.7 KB of LDS (the slots' places in the bin), three per CU
+    // (one per XCD) times 2^sub_shift workgroups per step of the grid; 40.5 KB of LDS (the slots' places in the bin, 9-bit digits): four per CU
     const dim3 grid(n_buckets ? (sub_shift ? ((((n_buckets + (1u << sub_shift) - 1u) >> sub_shift) + 7u) / 8u * 8u) << sub_shift : n_buckets)
                               : n_padded / 2048);
 #define CM3_LOCAL_(PART, QUANT, BAL, SUB, SK, SC, SPL, BOFS, NB, NEXT)                                                              \
